@@ -1,0 +1,485 @@
+"""Generates tests/golden/*.npz by running the REAL reference (TEST INFRASTRUCTURE).
+
+Run here, in the build container only (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [--only NAME]
+
+Only inputs/outputs (small arrays) are written; no reference source travels.
+Weights are never stored: both sides regenerate them from
+``vall_e_amd.weights.synth_state_dict(cfg, seed)``.
+
+Scenarios (names = file stems under tests/golden/):
+  qnt_enc_prompt    the codes of the reference's data/qnt.enc fixture (1x8x173 uint16), read
+                    with an opcode scanner that executes nothing (the file is a pickled
+                    object array; numpy's safe loader refuses it), + its phoneme ids
+  samplers_kat      known-answer vectors for vall_e/samplers.py processors
+  tiny_fwd          tiny model (d=256,h=4,L=2): embeddings, position ids, hidden states, logits
+  tiny_ar_nar       tiny model, ragged B=3: greedy AR + 7 NAR levels, margins
+  tiny_sampling     tiny model: greedy AR under rep-pen / length-pen / top-k / top-p, stop-token path
+  tiny_cfg          tiny model: AR + NAR with cfg_strength > 0
+  tiny_narlen       tiny model: NAR-len demasking (max_steps 6) + NAR levels
+  full_b1           BASELINE configs[0]: full model, qnt.enc prompt, 19 phonemes, AR 24 + NAR
+  full_b3           full model, ragged B=3, AR 12 + NAR
+  full_narlen       full model, B=2, NAR-len max_steps 4
+  full_bf16         full model in bf16: prefill + NAR-level logits (tolerance test)
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import pickletools
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "oracle"))
+
+import ref_harness as rh  # noqa: E402
+from vall_e_amd import config as vcfg  # noqa: E402
+from vall_e_amd.synth import synth_batch, synth_utterance, QNT_ENC_PHONEME_IDS  # noqa: E402
+from vall_e_amd.weights import synth_state_dict  # noqa: E402
+
+GOLD = ROOT / "tests" / "golden"
+WEIGHT_SEED = 1234
+
+
+# --------------------------------------------------------------------------- utils
+def save(name, **arrays):
+    GOLD.mkdir(parents=True, exist_ok=True)
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu()
+            v = v.float().numpy() if v.dtype == torch.bfloat16 else v.numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(GOLD / f"{name}.npz", **out)
+    size = (GOLD / f"{name}.npz").stat().st_size
+    print(f"[golden] {name}.npz  {size/1024:.1f} KiB  keys={sorted(out)}")
+
+
+def pack_list(prefix, tensors):
+    """list of ragged tensors -> {prefix_i: array}"""
+    return {f"{prefix}_{i}": t for i, t in enumerate(tensors)}
+
+
+def read_qnt_enc_codes(path):
+    """Extracts the uint16 code buffer from the pickled object array WITHOUT unpickling."""
+    raw = open(path, "rb").read()
+    assert raw[:6] == b"\x93NUMPY"
+    hlen = int.from_bytes(raw[8:10], "little")
+    body = raw[10 + hlen:]
+    ints, strs, codes = [], [], None
+    for op, arg, _ in pickletools.genops(body):
+        if op.name in ("BININT1", "BININT", "BININT2"):
+            ints.append(arg)
+        if op.name == "BINUNICODE":
+            strs.append(arg)
+        if op.name == "BINBYTES" and len(arg) == 2 * 8 * 173:
+            codes = np.frombuffer(arg, dtype="<u2").reshape(1, 8, 173).copy()
+    assert codes is not None
+    phonemes = strs[strs.index("phonemes") + 1]
+    return codes, phonemes
+
+
+_models = {}
+
+
+def get_ref_model(kind, dtype=torch.float32, **synth_kw):
+    key = (kind, dtype, tuple(sorted(synth_kw.items())))
+    if key in _models:
+        return _models[key]
+    mcfg = vcfg.repo_default_model() if kind == "full" else vcfg.tiny_model()
+    model = rh.build_reference_model(size=mcfg.size)
+    sd = synth_state_dict(mcfg, WEIGHT_SEED, **synth_kw)
+    missing = model.load_state_dict(sd, strict=True)
+    model = model.to(dtype).eval()
+    _models.clear()  # keep one model in memory at a time
+    _models[key] = (model, mcfg)
+    return model, mcfg
+
+
+class Recorder:
+    """Wraps Base.forward to keep a copy of what each forward produced."""
+
+    def __init__(self, ref, keep_rows="last"):
+        self.ref = ref
+        self.calls = []
+        self.keep_rows = keep_rows
+
+    def __enter__(self):
+        base = self.ref.models.base.Base
+        self._orig = base.forward
+        rec = self
+
+        def wrapped(self_, inputs, quant_levels=None, state=None, **kw):
+            out = rec._orig(self_, inputs, quant_levels=quant_levels, state=state, **kw)
+            entry = {"quant_levels": quant_levels}
+            if rec.keep_rows == "last":
+                entry["logits"] = [l[-1].detach().float().clone() for l in out.logits]
+            else:
+                entry["logits"] = [l.detach().float().clone() for l in out.logits]
+            rec.calls.append(entry)
+            return out
+
+        base.forward = wrapped
+        return self
+
+    def __exit__(self, *a):
+        self.ref.models.base.Base.forward = self._orig
+
+
+def top2_gap(row):
+    v = torch.topk(row.float(), 2).values
+    return float(v[0] - v[1])
+
+
+def to_model_inputs(phns, proms, langs):
+    return dict(phns_list=[p.clone() for p in phns], proms_list=[p.clone() for p in proms],
+                lang_list=[l.clone() for l in langs])
+
+
+def run_ar(model, phns, proms, langs, **kw):
+    with torch.inference_mode():
+        return model(task_list=["tts"] * len(phns), **to_model_inputs(phns, proms, langs),
+                     disable_tqdm=True, **kw)
+
+
+def run_nar(model, phns, proms, langs, resps, **kw):
+    with torch.inference_mode():
+        return model(task_list=["tts"] * len(phns), **to_model_inputs(phns, proms, langs),
+                     resps_list=[r.clone() for r in resps], disable_tqdm=True, **kw)
+
+
+def run_narlen(model, phns, proms, langs, lens, **kw):
+    with torch.inference_mode():
+        return model(task_list=["tts"] * len(phns), **to_model_inputs(phns, proms, langs),
+                     len_list=list(lens), disable_tqdm=True, **kw)
+
+
+def input_arrays(phns, proms, langs):
+    d = {}
+    d.update(pack_list("phn", phns)), d.update(pack_list("prom", proms)), d.update(pack_list("lang", langs))
+    d["batch"] = np.int64(len(phns))
+    return d
+
+
+# ----------------------------------------------------------------------- scenarios
+def scen_qnt_enc():
+    codes, phonemes = read_qnt_enc_codes(rh.REFERENCE_ROOT / "data" / "qnt.enc")
+    from tokenizers import Tokenizer
+    tok = Tokenizer.from_file(str(rh.REFERENCE_ROOT / "data" / "tokenizer.json"))
+    ids = tok.encode(phonemes).ids
+    # data.tokenize (vall_e/data.py:640-648) wraps with <bos>=1 / <eos>=2 via the tokenizer's template
+    if ids[0] != 1:
+        ids = [1] + ids + [2]
+    assert ids == QNT_ENC_PHONEME_IDS, ids
+    save("qnt_enc_prompt", codes=codes, phoneme_ids=np.array(ids, dtype=np.int64))
+
+
+def qnt_inputs():
+    z = np.load(GOLD / "qnt_enc_prompt.npz")
+    prom = torch.from_numpy(z["codes"][0].T.astype(np.int16)).contiguous()  # (173, 8)
+    phn = torch.tensor(z["phoneme_ids"], dtype=torch.uint8)
+    return [phn], [prom], [torch.tensor([0], dtype=torch.uint8)]
+
+
+def scen_samplers():
+    ref = rh.load_reference()
+    S = ref.samplers
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    logits = torch.randn(6, 1025, generator=g) * 2.0
+    out["logits"] = logits.clone()
+    prev_nar = torch.randint(0, 1024, (6,), generator=g)
+    prev_ar = torch.randint(0, 1024, (9,), generator=g)
+    prev_ar[3] = prev_ar[7]  # a repeated token compounds
+    out["prev_nar"], out["prev_ar"] = prev_nar, prev_ar
+    # repetition penalty: NAR mode (len(prev)==rows) and AR mode (1 row, many prev)
+    out["rep_nar"] = S.reptition_penalize(logits.clone(), previous=prev_nar, factor=1.3, decay=0.0)
+    out["rep_nar_decay"] = S.reptition_penalize(logits.clone(), previous=prev_nar, factor=1.2, decay=0.5)
+    out["rep_ar"] = S.reptition_penalize(logits[:1].clone(), previous=prev_ar, factor=1.25, decay=0.0)
+    out["rep_ar_decay"] = S.reptition_penalize(logits[:1].clone(), previous=prev_ar, factor=1.1, decay=0.25)
+    out["rep_ar_one_prev"] = S.reptition_penalize(logits[:1].clone(), previous=prev_ar[:1], factor=1.5, decay=0.0)
+    out["len_pos"] = S.length_penalize(logits[:1].clone(), length=10, factor=0.5, token=1024)
+    out["len_neg"] = S.length_penalize(logits[:1].clone(), length=10, factor=-0.5, token=1024)
+    out["ban"] = S.ban_tokens(logits[:, :1024].clone(), tokens=[1024])
+    out["topk"] = S.top_k_top_p_filtering(logits.clone(), top_k=20, top_p=1.0)
+    out["topp"] = S.top_k_top_p_filtering(logits.clone(), top_k=0, top_p=0.8)
+    out["topk_topp"] = S.top_k_top_p_filtering(logits.clone(), top_k=50, top_p=0.9)
+    out["top_no"] = S.top_no_logits_processing(logits.clone())
+    out["min_p"] = S.min_p_filtering(logits.clone(), min_p=0.05)
+    pos = [torch.randn(12, 1024, generator=g), torch.randn(9, 1024, generator=g)]
+    neg = [torch.randn(7, 1024, generator=g), torch.randn(9, 1024, generator=g)]
+    out["cfg_pos_0"], out["cfg_pos_1"], out["cfg_neg_0"], out["cfg_neg_1"] = pos[0].clone(), pos[1].clone(), neg[0].clone(), neg[1].clone()
+    r = S.cfg_logits([p.clone() for p in pos], [n.clone() for n in neg], strength=3.0, lens=[5, 9], rescale=0.75)
+    out["cfg_out_0"], out["cfg_out_1"] = r
+    r = S.cfg_logits([p.clone() for p in pos], [n.clone() for n in neg], strength=2.0, lens=[5, 9], rescale=0.0)
+    out["cfg_norescale_0"], out["cfg_norescale_1"] = r
+    save("samplers_kat", **out)
+
+
+def first_forward_probe(model, ref, phns, proms, langs, rows):
+    """One AR-style forward (empty resp): embeddings, pos ids, hidden states, logits."""
+    B = len(phns)
+    with torch.inference_mode():
+        resps = [torch.zeros(0, dtype=torch.int16) for _ in range(B)]
+        inputs = model.inputs(task_list=["tts"] * B, phns_list=phns, proms_list=proms, resps_list=resps,
+                              lang_list=langs, quant_levels=[0] * B)
+        x_list = model.inputs_to_embeddings(inputs, [0] * B)
+        x, mask = ref.models.base.list_to_tensor(x_list)
+        pos = model.inputs_to_position_ids(inputs, mask=mask)
+        hs = {}
+        h0 = model.model.layers[0].register_forward_hook(lambda m, i, o: hs.__setitem__("layer0", o[0].detach().clone()))
+        hn = model.model.norm.register_forward_hook(lambda m, i, o: hs.__setitem__("final", o.detach().clone()))
+        out = model.forward_super(inputs=inputs, quant_levels=[0] * B)
+        h0.remove(), hn.remove()
+    d = {"pos_ids": pos, "mask": mask}
+    for b in range(B):
+        T = x_list[b].shape[0]
+        rr = [r if r >= 0 else T + r for r in rows if -T <= r < T]
+        d[f"rows_{b}"] = np.array(rr)
+        d[f"emb_rows_{b}"] = x_list[b][rr]
+        d[f"emb_sum_{b}"] = x_list[b].double().sum(0)
+        d[f"layer0_rows_{b}"] = hs["layer0"][b, rr]
+        d[f"final_rows_{b}"] = hs["final"][b, rr]
+        d[f"logits_rows_{b}"] = out.logits[b][rr]
+        d[f"seq_len_{b}"] = np.int64(T)
+    return d
+
+
+def scen_tiny_fwd():
+    ref = rh.load_reference()
+    model, mcfg = get_ref_model("tiny")
+    phns, proms, langs = synth_batch(11, 2, n_phn=12, n_prom=20, ragged=True)
+    d = input_arrays(phns, proms, langs)
+    d.update(first_forward_probe(model, ref, phns, proms, langs, rows=list(range(0, 8)) + [-3, -2, -1]))
+    # one NAR-style forward at level 3 with full-T logits of item 0
+    g = torch.Generator().manual_seed(5)
+    resps = [torch.randint(0, 1024, (10 + 3 * i, 3), generator=g).to(torch.int16) for i in range(2)]
+    with torch.inference_mode():
+        inputs = model.inputs(task_list=["tts"] * 2, phns_list=phns, proms_list=proms, resps_list=resps,
+                              lang_list=langs, quant_levels=[3, 3])
+        x_list = model.inputs_to_embeddings(inputs, [3, 3])
+        out = model.forward_super(inputs=inputs, quant_levels=[3, 3])
+    d.update(pack_list("nar_resp", resps))
+    for b in range(2):
+        d[f"nar_emb_{b}"] = x_list[b]
+        d[f"nar_logits_{b}"] = out.logits[b]
+    save("tiny_fwd", **d)
+
+
+MIN_GAP = 2e-4  # greedy decisions closer than this are not a fair bit-exactness pin in fp32
+
+
+def ar_nar_scenario(name, kind, make_inputs, seed, steps, **kw):
+    """Tries input seeds seed, seed+1, ... until every greedy decision has a top-2 margin > MIN_GAP."""
+    for s in range(seed, seed + 16):
+        phns, proms, langs = make_inputs(s)
+        d, gap = _ar_nar_scenario(name, kind, phns, proms, langs, steps, **kw)
+        if gap > MIN_GAP:
+            d["input_seed"] = np.int64(s)
+            save(name, **d)
+            return
+        print(f"  [{name}] seed {s}: min gap {gap:.2e} too small, trying next seed")
+    raise RuntimeError(f"{name}: no seed with margin > {MIN_GAP}")
+
+
+def _ar_nar_scenario(name, kind, phns, proms, langs, steps, ar_kw=None, nar_kw=None, nar=True, keep_logit_steps=8,
+                     model_kw=None):
+    ref = rh.load_reference()
+    model, mcfg = get_ref_model(kind, **(model_kw or {}))
+    ar_kw = dict(ar_kw or {})
+    nar_kw = dict(nar_kw or {})
+    d = input_arrays(phns, proms, langs)
+    d["steps"] = np.int64(steps)
+    min_gap = 1e9
+    with Recorder(ref) as rec:
+        codes = run_ar(model, phns, proms, langs, max_duration=steps, temperature=0.0, **ar_kw)
+    B = len(phns)
+    pos_calls = [c for c in rec.calls]
+    if ar_kw.get("cfg_strength", 0) > 0:
+        pos_calls = rec.calls[0::2]
+    else:
+        gaps = np.array([[top2_gap(c["logits"][b]) for b in range(B)] for c in pos_calls])
+        d["ar_top2_gap"] = gaps
+        d["ar_last_logits"] = torch.stack([torch.stack(c["logits"]) for c in pos_calls[:keep_logit_steps]])
+        print(f"  [{name}] AR min top-2 gap {gaps.min():.3e}")
+        min_gap = min(min_gap, float(gaps.min()))
+    d.update(pack_list("ar_codes", codes))
+    print(f"  [{name}] AR lens {[len(c) for c in codes]} head {codes[0][:8].tolist()}")
+    if nar:
+        with Recorder(ref, keep_rows="all") as rec:
+            full = run_nar(model, phns, proms, langs, codes, temperature=0.0, **nar_kw)
+        d.update(pack_list("nar_codes", full))
+        if not nar_kw.get("cfg_strength", 0) > 0:
+            gaps = []
+            for lvl, c in enumerate(rec.calls):
+                for b in range(B):
+                    R = len(codes[b])
+                    if R == 0:
+                        continue
+                    rows = c["logits"][b][-R:]
+                    v = torch.topk(rows, 2, dim=-1).values
+                    gaps.append(float((v[:, 0] - v[:, 1]).min()))
+            d["nar_min_top2_gap"] = np.array(gaps)
+            print(f"  [{name}] NAR min top-2 gap {min(gaps):.3e}")
+            min_gap = min(min_gap, min(gaps))
+    for k, v in {**ar_kw, **{"nar_" + a: b for a, b in nar_kw.items()}}.items():
+        d["kw_" + k] = np.float64(v)
+    return d, min_gap
+
+
+def scen_tiny_ar_nar():
+    mk = lambda s: synth_batch(s, 3, n_phn=14, n_prom=24, ragged=True)
+    ar_nar_scenario("tiny_ar_nar", "tiny", mk, 21, steps=32)
+
+
+def scen_tiny_sampling():
+    mk = lambda s: synth_batch(s, 2, n_phn=10, n_prom=16, ragged=True)
+    ar_nar_scenario("tiny_sampling_rep", "tiny", mk, 31, steps=24,
+                    ar_kw=dict(repetition_penalty=1.3, repetition_penalty_decay=0.25), nar=False)
+    ar_nar_scenario("tiny_sampling_topk", "tiny", mk, 31, steps=16,
+                    ar_kw=dict(top_k=5, top_p=0.7, repetition_penalty=1.15), nar=False)
+    # stop-token path: positive stop bias + negative length penalty makes the stop logit grow with length
+    ar_nar_scenario("tiny_sampling_stop", "tiny", mk, 31, steps=40,
+                    ar_kw=dict(length_penalty=-1.0), nar=True, model_kw=dict(stop_bias=0.6))
+
+
+def scen_tiny_cfg():
+    mk = lambda s: synth_batch(s, 2, n_phn=10, n_prom=16, ragged=True)
+    ar_nar_scenario("tiny_cfg", "tiny", mk, 41, steps=12,
+                    ar_kw=dict(cfg_strength=3.0), nar_kw=dict(cfg_strength=2.0), nar=True)
+
+
+def narlen_scenario(name, kind, phns, proms, langs, lens, max_steps, **kw):
+    """NAR-len: records the final codes plus, per demasking step, the ids of the filtered
+    sample and the scores of the unfiltered one (ar_nar.py:436-462), and audits that the
+    lowest-k score selection (ar_nar.py:358) never cuts through a tie."""
+    import math
+    ref = rh.load_reference()
+    model, mcfg = get_ref_model(kind)
+    d = input_arrays(phns, proms, langs)
+    d["lens"] = np.array(lens)
+    d["max_steps"] = np.int64(max_steps)
+    base = ref.models.base.Base
+    orig_sample = base.sample
+    samples = []
+
+    def wrapped_sample(self_, *a, **k):
+        out = orig_sample(self_, *a, **k)
+        samples.append(([i.clone() for i in out.ids], [s.clone() for s in out.scores]))
+        return out
+
+    base.sample = wrapped_sample
+    try:
+        with Recorder(ref, keep_rows="all") as rec:
+            full = run_narlen(model, phns, proms, langs, lens, max_steps=max_steps, temperature=0.0, **kw)
+    finally:
+        base.sample = orig_sample
+    d.update(pack_list("codes", full))
+    d["n_forward_calls"] = np.int64(len(rec.calls))
+    d["level0_first_step_logits_0"] = rec.calls[0]["logits"][0][-lens[0]:]
+    B = len(lens)
+    min_cut = 1e9
+    for step in range(max_steps):
+        ids, _ = samples[2 * step]
+        _, sc = samples[2 * step + 1]
+        for b in range(B):
+            d[f"step{step}_ids_{b}"] = ids[b]
+            d[f"step{step}_scores_{b}"] = sc[b]
+        if step + 1 < max_steps:  # scores of this step choose the next step's mask
+            t = torch.linspace(0.0, 1.0, max_steps)[step + 1]
+            noise_p = math.cos(t * math.pi * 0.5)
+            for b in range(B):
+                n = lens[b]
+                k = max(1, min(int(noise_p * n), n - (step + 1)))
+                srt = torch.sort(sc[b].float()).values
+                if k < n:
+                    min_cut = min(min_cut, float(srt[k] - srt[k - 1]))
+    d["min_cut_gap"] = np.float64(min_cut)
+    print(f"  [{name}] forwards {len(rec.calls)} min score gap at the mask cut {min_cut:.3e} codes0 {full[0][:3].tolist()}")
+    if min_cut <= 1e-6:
+        raise RuntimeError("mask cut goes through a (near-)tie: pick other inputs")
+    save(name, **d)
+
+
+def scen_tiny_narlen():
+    phns, proms, langs = synth_batch(51, 2, n_phn=10, n_prom=16, ragged=True)
+    narlen_scenario("tiny_narlen", "tiny", phns, proms, langs, lens=[18, 25], max_steps=6)
+
+
+def scen_full_b1():
+    ref = rh.load_reference()
+    phns, proms, langs = qnt_inputs()
+    model, mcfg = get_ref_model("full")
+    d = first_forward_probe(model, ref, phns, proms, langs, rows=[0, 1, 18, 19, 20, 21, 22, 23, 24, 100, -2, -1])
+    save("full_b1_fwd", **d)
+    ar_nar_scenario("full_b1", "full", lambda s: (phns, proms, langs), 0, steps=24)
+
+
+def scen_full_b3():
+    mk = lambda s: synth_batch(s, 3, n_phn=30, n_prom=60, ragged=True)
+    ar_nar_scenario("full_b3", "full", mk, 61, steps=12)
+
+
+def scen_full_narlen():
+    phns, proms, langs = synth_batch(71, 2, n_phn=20, n_prom=40, ragged=True)
+    narlen_scenario("full_narlen", "full", phns, proms, langs, lens=[20, 26], max_steps=4)
+
+
+def scen_full_bf16():
+    ref = rh.load_reference()
+    phns, proms, langs = qnt_inputs()
+    model, mcfg = get_ref_model("full", dtype=torch.bfloat16)
+    d = {}
+    with torch.inference_mode():
+        B = 1
+        resps = [torch.zeros(0, dtype=torch.int16)]
+        inputs = model.inputs(task_list=["tts"], phns_list=phns, proms_list=proms, resps_list=resps,
+                              lang_list=langs, quant_levels=[0])
+        out = model.forward_super(inputs=inputs, quant_levels=[0])
+        d["ar_logits_last16"] = out.logits[0][-16:].float()
+        g = torch.Generator().manual_seed(9)
+        r = [torch.randint(0, 1024, (24, 2), generator=g).to(torch.int16)]
+        inputs = model.inputs(task_list=["tts"], phns_list=phns, proms_list=proms, resps_list=r,
+                              lang_list=langs, quant_levels=[2])
+        out = model.forward_super(inputs=inputs, quant_levels=[2])
+        d["nar_resp"] = r[0]
+        d["nar_logits"] = out.logits[0][-24:].float()
+    save("full_bf16", **d)
+
+
+SCENARIOS = {
+    "qnt_enc_prompt": scen_qnt_enc,
+    "samplers_kat": scen_samplers,
+    "tiny_fwd": scen_tiny_fwd,
+    "tiny_ar_nar": scen_tiny_ar_nar,
+    "tiny_sampling": scen_tiny_sampling,
+    "tiny_cfg": scen_tiny_cfg,
+    "tiny_narlen": scen_tiny_narlen,
+    "full_b1": scen_full_b1,
+    "full_b3": scen_full_b3,
+    "full_narlen": scen_full_narlen,
+    "full_bf16": scen_full_bf16,
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    torch.manual_seed(0)
+    for name, fn in SCENARIOS.items():
+        if args.only and name not in args.only:
+            continue
+        print(f"[golden] scenario {name}")
+        fn()
+
+
+if __name__ == "__main__":
+    main()

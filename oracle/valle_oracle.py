@@ -1,0 +1,491 @@
+"""CPU restatement of the reference's AR+NAR forward path  (TEST INFRASTRUCTURE ONLY).
+
+This file is the parity oracle.  It is written from scratch in plain PyTorch (CPU) and
+restates, function by function, what the reference computes on this path; it is pinned by
+the golden vectors in tests/golden/ that oracle/gen_golden.py produced by running the real
+reference in the build container (tests/test_oracle_vs_golden.py).  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import it; the product
+(vall_e_amd) never does and fails loudly if its HIP library is missing.
+
+Layout differences from the reference are deliberate (this is a restatement, not a copy):
+utterances are processed as a token-packed matrix (sum(T_i), d) -- linear layers run on the
+packed matrix, attention per utterance -- instead of a right-padded (B, Tmax, d) tensor with
+an additive (B,1,T,T) mask.  Under the reference's all-causal masks (base.py:1233) a valid
+row never sees a padded key, so both give the same values.
+
+Reference map (all paths relative to /root/reference/vall_e):
+  segment order / classifier level     models/base.py:560-735   -> ``plan_sequence``
+  embedding sums, sep join             models/base.py:101-110, :147-175, :774-922 -> ``embed_sequence``
+  per-segment position ids             models/base.py:949-996   -> ``plan_sequence`` (pos)
+  RMSNorm / RoPE / attention / GEGLU   models/arch/llama.py:48-132, :224-477, :479-566 -> ``Oracle.stack``
+  classifier heads                     models/base.py:179-231   -> ``Oracle.head``
+  sampler chain                        models/base.py:1280-1430, samplers.py -> ``sample`` and helpers
+  AR loop / NAR levels / NAR-len       models/ar_nar.py:588-890, :466-586, :233-464
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+TASK_SYMMAP = {"tts": 0, "tts-c": 1, "ns": 2, "sr": 3, "tse": 4, "soe": 5, "mask": 6, "eoe": 7, "stt": 8}  # data.py:670-688
+
+
+# ------------------------------------------------------------------ sequence planning
+@dataclass
+class Segment:
+    kind: str            # phn | lang | quant_level | prom | resp | len | task
+    ids: torch.Tensor    # (n,) or (n, levels) integer codes
+
+
+@dataclass
+class Plan:
+    segments: list
+    head: str            # classifier level name
+    quant_level: int
+    pos: torch.Tensor    # (T,) int64 position ids
+    out_len: int         # length of the output segment
+
+
+def plan_sequence(phn, lang, prom, resp, quant_level, *, timestep=False, task="tts", unified_pos=False):
+    """Ordered segments of one utterance + per-segment position ids.
+
+    TTS order: phn, lang, quant_level, prom, resp (base.py:605-649); every segment but the
+    last is followed by one ``sep`` row (base.py:101-110), which the position ids of the
+    non-output segments count as one extra position (base.py:984)."""
+    if task != "tts":
+        raise NotImplementedError("oracle covers the tts layout (AR, NAR, NAR-len)")
+    segs = []
+    if phn is not None:
+        segs.append(Segment("phn", phn.long()))
+    if lang is not None:
+        segs.append(Segment("lang", lang.long()))
+    segs.append(Segment("quant_level", torch.tensor([quant_level])))
+    head = "AR:0:0" if quant_level == 0 else f"NAR:{quant_level-1}:{quant_level}"
+    if prom is not None:
+        segs.append(Segment("prom", prom.long()))
+    if timestep:
+        head = "NAR:0:0"
+    if resp is not None:
+        segs.append(Segment("resp", resp.long()))
+    pos = []
+    for s in segs:
+        n = s.ids.shape[0]
+        pos.append(torch.arange(n + (0 if s.kind == "resp" else 1)))
+    pos = torch.cat(pos)
+    T = sum(s.ids.shape[0] for s in segs) + len(segs) - 1
+    if segs[-1].kind != "resp":   # no output segment: the trailing +1 has no sep row behind it
+        pos = pos[:T]
+    if unified_pos:
+        pos = torch.arange(T)
+    assert pos.shape[0] == T, (pos.shape, T)
+    return Plan(segs, head, quant_level, pos, segs[-1].ids.shape[0] if segs[-1].kind == "resp" else 0)
+
+
+# ------------------------------------------------------------------------- samplers
+def repetition_penalize(logits, previous, factor=1.0, decay=0.0):
+    """samplers.py:16-50 (limit/one_time unused on this path).  In place, like the reference."""
+    if factor == 1.0 or previous is None:
+        return logits
+    n = previous.shape[0]
+    is_nar = n == logits.shape[0]
+    for i in range(n):
+        tok = int(previous[i])
+        distance = n - i
+        start = i + 1 if (is_nar and i < logits.shape[0]) else None
+        logits[start:, tok] /= factor * (distance ** decay)
+    return logits
+
+
+def length_penalize(logits, length, factor=0.0, token=-1):
+    """samplers.py:56-61."""
+    if factor == 0.0:
+        return logits
+    logits[:, token] /= (length ** factor)
+    return logits
+
+
+def top_k_top_p_filter(logits, top_k=0, top_p=1.0):
+    """samplers.py:93-125 (min_tokens=1).  In place."""
+    if top_k > 0:
+        k = min(max(top_k, 1), logits.size(-1))
+        kth = torch.topk(logits, k)[0][..., -1, None]
+        logits[logits < kth] = -float("inf")
+    if top_p < 1.0:
+        s_logits, s_idx = torch.sort(logits, descending=True)
+        cum = torch.cumsum(F.softmax(s_logits, dim=-1), dim=-1)
+        remove = cum > top_p
+        remove[..., 1:] = remove[..., :-1].clone()
+        remove[..., 0] = False
+        remove = remove.scatter(1, s_idx, remove)
+        logits[remove] = -float("inf")
+    return logits
+
+
+def min_p_filter(logits, min_p=0.0, keep=32):
+    """samplers.py:74-90."""
+    if min_p <= 0.0:
+        return logits
+    probs = torch.softmax(logits, dim=-1)
+    thr = min_p * probs.max(dim=-1, keepdim=True).values
+    order = torch.argsort(logits, descending=True, dim=-1)
+    rem = torch.gather(probs < thr, -1, order)
+    rem[..., :keep] = False
+    rem = rem.scatter(1, order, rem)
+    return logits.masked_fill(rem, -float("inf"))
+
+
+def top_n_sigma(logits, n=1.0):
+    """samplers.py:164-172 (unbiased std)."""
+    m = logits.max(dim=-1, keepdim=True).values
+    sd = torch.std(logits, dim=-1, keepdim=True)
+    return torch.where(logits >= m - n * sd, logits, torch.full_like(logits, -float("inf")))
+
+
+def cfg_combine(pos_logits, null_logits, strength, lens, rescale=0.0):
+    """samplers.py:177-191: in place on the last ``len`` rows of each positive logit tensor.
+    For 2-D logits ``dims=()`` makes std a GLOBAL unbiased std over rows x vocab."""
+    for i, n in enumerate(lens):
+        pos = pos_logits[i][-n:, :]
+        neg = null_logits[i][-n:, :]
+        mix = neg + (pos - neg) * strength
+        if rescale > 0:
+            mix = mix * (rescale * (pos.std() / mix.std()) + (1 - rescale))
+        pos_logits[i][-n:, :] = mix
+    return pos_logits
+
+
+def sample(logits, prev_list=None, quant_levels=None, *, causal_size=1, stop_token=1024, generator=None,
+           temperature=1.0, min_temperature=-1.0, top_k=-100, top_p=1.0, min_p=0.0,
+           repetition_penalty=1.0, repetition_penalty_decay=0.0, length_penalty=0.0, top_no=1.0, **_unused):
+    """Base.sample (base.py:1280-1430), basic branch (no beam / mirostat / DRY / entropix).
+    Returns (ids, processed_logits, scores)."""
+    if min_temperature < 0:
+        min_temperature = temperature
+    if prev_list is not None:
+        prev_list = [p if p.dim() == 1 else p[:, -1] for p in prev_list]
+    if quant_levels is not None:
+        logits = [l[-len(p):] for l, p in zip(logits, prev_list)]          # :1354-1356
+    else:
+        logits = [l[-causal_size:] for l in logits]                          # :1358-1360
+    # ban_tokens(stop) for NAR is a no-op: ``logits.shape[-1] >= token`` always holds (samplers.py:67)
+    if prev_list is not None and repetition_penalty != 1.0:
+        logits = [repetition_penalize(l, p, repetition_penalty, repetition_penalty_decay) for l, p in zip(logits, prev_list)]
+    if quant_levels is None and prev_list is not None and length_penalty != 0.0:
+        logits = [length_penalize(l, len(p) + 1, length_penalty, stop_token) for l, p in zip(logits, prev_list)]
+    if min_p > 0.0:
+        logits = [min_p_filter(l, min_p) for l in logits]
+    if top_k > 0 or top_p < 1.0:
+        logits = [top_k_top_p_filter(l, top_k, top_p) for l in logits]
+    if abs(temperature - min_temperature) >= 0.001:
+        raise NotImplementedError("dynamic temperature is outside the restated path")
+    elif temperature > 0.0:
+        logits = [l / temperature for l in logits]
+    if top_no > 0.0:
+        logits = [top_n_sigma(l) for l in logits]
+    if temperature <= 0.0:
+        ids = [l.argmax(dim=-1) for l in logits]
+    else:
+        ids = []
+        for l in logits:
+            p = torch.softmax(l.float(), dim=-1)
+            ids.append(torch.multinomial(p, 1, generator=generator).squeeze(-1))
+    scores = [F.softmax(l, dim=-1).gather(1, t.unsqueeze(-1)).squeeze(-1) for l, t in zip(logits, ids)]
+    return ids, logits, scores
+
+
+def convert_kwargs(kwargs, prefix):
+    """utils/utils.py:46-56."""
+    out = dict(kwargs)
+    for k in list(out):
+        if k.startswith(prefix):
+            out[k[len(prefix):]] = out.pop(k)
+    return out
+
+
+def clamp(n, lo, hi):
+    return max(lo, min(n, hi))
+
+
+# ---------------------------------------------------------------------------- model
+class Oracle:
+    def __init__(self, cfg, state_dict, dtype=torch.float32, threads=None):
+        from vall_e_amd.weights import classifier_layout
+        self.cfg = cfg
+        self.dtype = dtype
+        self.w = {k: v.to(dtype) for k, v in state_dict.items()}
+        self.d = cfg.dim
+        self.H = cfg.heads
+        self.Dh = cfg.dim // cfg.heads
+        self.L = cfg.layers
+        self.n_levels = cfg.resp_levels
+        self.stop_token = cfg.audio_tokens
+        self.mask_token = cfg.audio_tokens
+        self.causal_size = cfg.experimental.causal_size
+        self.unified_pos = cfg.experimental.unified_position_ids
+        self.emb_names, _, self.cls_names, self.cls_tokens = classifier_layout(cfg)
+        self.eps = 1e-6
+        self.theta = 10000.0
+        self.inv_freq = 1.0 / (self.theta ** (torch.arange(0, self.Dh, 2, dtype=torch.int64).float() / self.Dh))
+        if threads:
+            torch.set_num_threads(threads)
+
+    # -- embeddings (base.py:774-922) ---------------------------------------------
+    def _audio_sum(self, table_prefix, first, codes, n):
+        acc = None
+        for l in range(n):
+            e = self.w[f"{table_prefix}.embeddings.{first + l}.weight"][codes[:, l]]
+            acc = e if acc is None else acc + e
+        return acc
+
+    def embed_segment(self, seg, plan):
+        q = plan.quant_level
+        ids = seg.ids
+        if seg.kind == "phn":
+            return self.w["text_emb.weight"][ids]
+        if seg.kind == "lang":
+            return self.w["langs_emb.weight"][ids]
+        if seg.kind == "quant_level":
+            return self.w["rvq_l_emb.weight"][ids]
+        if seg.kind == "len":
+            return self.w["len_emb.weight"][ids]
+        if seg.kind == "prom":
+            if ids.dim() == 1:
+                return self.w["proms_emb.embeddings.0.weight"][ids]
+            return self._audio_sum("proms_emb", 0, ids, 1 if q == 0 else q)          # base.py:790-794
+        if seg.kind == "resp":
+            if plan.head == "NAR:0:0":                                               # base.py:869-874
+                col = ids if ids.dim() == 1 else ids[:, q]
+                return self.w[f"resps_emb.embeddings.{self.emb_names.index('NAR:0:0')}.weight"][col]
+            if q == 0:                                                               # base.py:893-899
+                col = ids if ids.dim() == 1 else ids[:, 0]
+                return self.w["resps_emb.embeddings.0.weight"][col]
+            if ids.dim() == 1:
+                ids = ids[:, None]
+            return self._audio_sum("resps_emb", 1, ids, q)
+        raise ValueError(seg.kind)
+
+    def embed_sequence(self, plan):
+        parts = []
+        sep = self.w["sep"][None]
+        for i, seg in enumerate(plan.segments):
+            if i:
+                parts.append(sep)
+            parts.append(self.embed_segment(seg, plan).reshape(-1, self.d))
+        return torch.cat(parts, dim=0)
+
+    # -- transformer stack (arch/llama.py) ---------------------------------------------
+    def rms_norm(self, x, w):
+        xf = x.float()
+        xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + self.eps)
+        return w * xf.to(x.dtype)
+
+    def rope(self, pos):
+        freqs = pos.float()[:, None] * self.inv_freq[None, :]
+        emb = torch.cat((freqs, freqs), dim=-1)
+        return emb.cos().to(self.dtype), emb.sin().to(self.dtype)
+
+    @staticmethod
+    def _rot(x, cos, sin):
+        h = x.shape[-1] // 2
+        rot = torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+        return x * cos + rot * sin
+
+    def stack(self, x, pos, lens, kv=None, layer_probe=None):
+        """x: packed (sum(lens), d); pos: packed position ids; lens: rows per utterance.
+        kv: optional list (per layer) of per-utterance [K, V] caches that are appended to
+        (KV-cache mode); attention then runs each new row against cache + new rows."""
+        cos, sin = self.rope(pos)
+        cos, sin = cos[:, None, :], sin[:, None, :]
+        offs = [0]
+        for n in lens:
+            offs.append(offs[-1] + n)
+        scale = 1.0 / math.sqrt(self.Dh)
+        for l in range(self.L):
+            p = f"model.layers.{l}."
+            h = self.rms_norm(x, self.w[p + "input_layernorm.weight"])
+            q = F.linear(h, self.w[p + "self_attn.q_proj.weight"]).view(-1, self.H, self.Dh)
+            k = F.linear(h, self.w[p + "self_attn.k_proj.weight"]).view(-1, self.H, self.Dh)
+            v = F.linear(h, self.w[p + "self_attn.v_proj.weight"]).view(-1, self.H, self.Dh)
+            q, k = self._rot(q, cos, sin), self._rot(k, cos, sin)
+            outs = []
+            for b, n in enumerate(lens):
+                qb = q[offs[b]:offs[b + 1]].transpose(0, 1)
+                kb = k[offs[b]:offs[b + 1]].transpose(0, 1)
+                vb = v[offs[b]:offs[b + 1]].transpose(0, 1)
+                past = 0
+                if kv is not None:
+                    if kv[l][b] is not None:
+                        past = kv[l][b][0].shape[1]
+                        kb = torch.cat([kv[l][b][0], kb], dim=1)
+                        vb = torch.cat([kv[l][b][1], vb], dim=1)
+                    kv[l][b] = [kb, vb]
+                Tk = kb.shape[1]
+                mask = torch.ones(n, Tk, dtype=torch.bool).tril(diagonal=past)
+                att = (qb @ kb.transpose(1, 2)) * scale
+                att = att.masked_fill(~mask, float("-inf"))
+                att = torch.softmax(att.float(), dim=-1).to(qb.dtype)
+                outs.append((att @ vb).transpose(0, 1).reshape(n, self.d))
+            a = torch.cat(outs, dim=0)
+            x = x + F.linear(a, self.w[p + "self_attn.o_proj.weight"])
+            h = self.rms_norm(x, self.w[p + "post_attention_layernorm.weight"])
+            g = F.gelu(F.linear(h, self.w[p + "mlp.gate_proj.weight"]))
+            u = F.linear(h, self.w[p + "mlp.up_proj.weight"])
+            x = x + F.linear(g * u, self.w[p + "mlp.down_proj.weight"])
+            if layer_probe is not None and l == 0:
+                layer_probe["layer0"] = x
+        x = self.rms_norm(x, self.w["model.norm.weight"])
+        if layer_probe is not None:
+            layer_probe["final"] = x
+        return x
+
+    def head(self, x, name):
+        k = self.cls_names.index(name)
+        return F.linear(x, self.w[f"classifiers.proj.{k}.weight"], self.w.get(f"classifiers.proj.{k}.bias"))
+
+    # -- one forward over a batch of plans: list of (T_i, V) logits (Base.forward) --------------
+    def forward(self, plans, rows=None, probe=None):
+        xs = [self.embed_sequence(p) for p in plans]
+        lens = [x.shape[0] for x in xs]
+        hid = self.stack(torch.cat(xs), torch.cat([p.pos for p in plans]), lens, layer_probe=probe)
+        out, o = [], 0
+        for i, (p, n) in enumerate(zip(plans, lens)):
+            hi = hid[o:o + n]
+            o += n
+            if rows is not None:
+                hi = hi[-rows[i]:] if rows[i] > 0 else hi[:0]
+            out.append(self.head(hi, p.head))
+        return out
+
+    def _plans(self, phns, langs, proms, resps, q, timestep=False):
+        B = len(resps)
+        return [plan_sequence(None if phns is None else phns[i], None if langs is None else langs[i],
+                              None if proms is None else proms[i], resps[i], q, timestep=timestep,
+                              unified_pos=self.unified_pos) for i in range(B)]
+
+    # -- AR (ar_nar.py:588-890, tts task) ---------------------------------------------
+    def ar(self, phns, proms, langs, *, max_duration=500, use_cache=False, return_logits=False, generator=None, **kw):
+        kw = convert_kwargs(dict(kw), "ar_")
+        temperature = kw.get("temperature", 1.0)
+        cfg_strength = kw.get("cfg_strength", 0.0)
+        cfg_rescale = kw.pop("cfg_rescale", 0.7)
+        B = len(phns)
+        seqs = [torch.zeros(0, dtype=torch.int64) for _ in range(B)]
+        stopped = [False] * B
+        null_phn = [torch.tensor([1, 2]) for _ in range(B)]
+        last_logits = []
+        kv = [[None] * B for _ in range(self.L)] if use_cache else None
+        for n in range(max_duration // max(1, self.causal_size)):
+            if use_cache and cfg_strength > 0:
+                raise NotImplementedError
+            if use_cache:
+                logits = self._forward_cached(phns, langs, proms, seqs, kv, first=(n == 0))
+            else:
+                logits = self.forward(self._plans(phns, langs, proms, seqs, 0), rows=[len(s) + 1 for s in seqs])
+            if cfg_strength > 0:
+                null = self.forward(self._plans(null_phn, langs, None, seqs, 0), rows=[len(s) + 1 for s in seqs])
+                logits = cfg_combine(logits, null, cfg_strength, [len(s) + 1 for s in seqs], cfg_rescale)
+            if return_logits:
+                last_logits.append(torch.stack([l[-1].float() for l in logits]))
+            ids, _, _ = sample(logits, prev_list=seqs, causal_size=self.causal_size, stop_token=self.stop_token,
+                               generator=generator, **kw)
+            for i in range(B):
+                if self.stop_token in ids[i]:
+                    stopped[i] = True
+                seqs[i] = torch.cat([seqs[i], ids[i].long()])
+            if all(stopped):
+                break
+        out = []
+        for s in seqs:
+            hit = (s == self.stop_token).nonzero()
+            out.append(s if len(hit) == 0 else s[: int(hit.min())])
+        return (out, last_logits) if return_logits else out
+
+    def _forward_cached(self, phns, langs, proms, seqs, kv, first):
+        """KV-cache step: prefill everything on the first call, afterwards only the newest row."""
+        plans = self._plans(phns, langs, proms, seqs, 0)
+        if first:
+            xs = [self.embed_sequence(p) for p in plans]
+            pos = [p.pos for p in plans]
+        else:
+            xs = [self.embed_sequence(p)[-1:] for p in plans]
+            pos = [p.pos[-1:] for p in plans]
+        lens = [x.shape[0] for x in xs]
+        hid = self.stack(torch.cat(xs), torch.cat(pos), lens, kv=kv)
+        out, o = [], 0
+        for p, n in zip(plans, lens):
+            out.append(self.head(hid[o + n - 1:o + n], p.head))
+            o += n
+        return out
+
+    # -- NAR levels (ar_nar.py:466-586) ---------------------------------------------
+    def nar(self, phns, proms, langs, resps, *, generator=None, **kw):
+        kw = convert_kwargs(dict(kw), "nar_")
+        max_levels = kw.get("max_levels", 0) or (self.cfg.max_levels - 1)
+        cfg_strength = kw.get("cfg_strength", 0.0)
+        cfg_rescale = kw.pop("cfg_rescale", 0.7)
+        B = len(resps)
+        prev = [r[:, None] if r.dim() == 1 else r for r in resps]
+        prev = [p.long() for p in prev]
+        null_phn = [torch.tensor([1, 2]) for _ in range(B)]
+        for _ in range(max_levels):
+            level = prev[0].shape[-1]
+            if level >= max_levels + 1:
+                break
+            R = [p.shape[0] for p in prev]
+            logits = self.forward(self._plans(phns, langs, proms, prev, level), rows=R)
+            if cfg_strength > 0:
+                null = self.forward(self._plans(null_phn, langs, None, prev, level), rows=R)
+                logits = cfg_combine(logits, null, cfg_strength, R, cfg_rescale)
+            ids, _, _ = sample(logits, prev_list=prev, quant_levels=[level] * B, stop_token=self.stop_token,
+                               generator=generator, **kw)
+            prev = [torch.cat([p, t[:, None].long()], dim=-1) for p, t in zip(prev, ids)]
+        return prev
+
+    # -- NAR-len level 0 demasking (ar_nar.py:233-464) --------------------------------
+    def nar_masked(self, phns, proms, langs, lens, *, generator=None, **kw):
+        kw = convert_kwargs(dict(kw), "ar_")
+        min_len = kw.pop("min_duration", 1)
+        max_len = kw.pop("max_duration", 500)
+        max_steps = kw.get("max_steps", 25)
+        annealed = kw.get("annealed_sampling", True)
+        temperature = kw.pop("temperature", 0.0)
+        min_cfg = kw.get("minimum_cfg_strength", 2.5)
+        cfg_strength = max(kw.get("cfg_strength", min_cfg), min_cfg)
+        cfg_rescale = kw.pop("cfg_rescale", 0.75)
+        start, end = kw.get("denoise_start", 0.0), kw.get("denoise_end", 1.0)
+        max_steps = math.floor(max_steps * (end - start))
+        remask = kw.get("sampling_scores_remask", False)
+        lens = [clamp(int(l), min_len, max_len) for l in lens]
+        B = len(lens)
+        resps = [torch.full((n,), self.mask_token, dtype=torch.int64) for n in lens]
+        scores = [torch.ones(n, dtype=torch.float32) for n in lens]
+        null_phn = [torch.tensor([1, 2]) for _ in range(B)]
+        for step, t in enumerate(torch.linspace(start, end, max_steps)):
+            noise_p = math.cos(t * math.pi * 0.5)
+            mask_p = noise_p + (1.0 / (max_steps * 2) if remask else 0)
+            prev = resps
+            idx = [s.topk(clamp(int(mask_p * n), 1, n - step), dim=-1, largest=False).indices for s, n in zip(scores, lens)]
+            resps = [r.scatter(0, i, self.mask_token) for r, i in zip(resps, idx)]
+            is_masked = [r == self.mask_token for r in resps]
+            temp = temperature * (1.0 - float(t)) if annealed else temperature
+            logits = self.forward(self._plans(phns, langs, proms, resps, 0, timestep=True), rows=lens)
+            if cfg_strength > 0:
+                null = self.forward(self._plans(null_phn, langs, None, resps, 0, timestep=True), rows=lens)
+                logits = cfg_combine(logits, null, cfg_strength, lens, cfg_rescale)
+            # the reference samples twice on the SAME tensors; in-place processors (rep-pen,
+            # top-k/top-p) therefore act twice before the "unfiltered" score pass
+            ids, _, _ = sample(logits, prev_list=prev, quant_levels=[0] * B, stop_token=self.stop_token,
+                               generator=generator, temperature=temp, **kw)
+            _, _, sc = sample(logits, prev_list=prev, quant_levels=[0] * B, stop_token=self.stop_token,
+                              temperature=0.0, **kw)
+            resps = [torch.where(m, i, r) for m, i, r in zip(is_masked, ids, resps)]
+            scores = [s.float() for s in sc]
+        return resps
+
+    def nar_len(self, phns, proms, langs, lens, **kw):
+        """AR_NAR.forward with len_list (ar_nar.py:485-496 then the level loop)."""
+        level0 = self.nar_masked(phns, proms, langs, lens, **dict(kw))
+        return self.nar(phns, proms, langs, level0, **kw)

@@ -1,0 +1,189 @@
+"""The CPU restatement (oracle/) against vectors produced by the real reference.
+
+Everything here runs on CPU.  Golden files come from oracle/gen_golden.py (reference imported
+in the build container); this is what pins the oracle before any HIP result is trusted.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_inputs, qnt_inputs, model_cfg, synth_weights
+import valle_oracle as vo
+
+
+def make_oracle(kind, dtype=torch.float32, **kw):
+    return vo.Oracle(model_cfg(kind), synth_weights(kind, **kw), dtype=dtype)
+
+
+def assert_close(a, b, rtol=2e-4, atol=2e-4):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape
+    err = (a - b).abs().max().item()
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), f"max abs err {err}"
+
+
+def test_samplers_known_answers():
+    z = load_golden("samplers_kat")
+    lg = torch.from_numpy(z["logits"])
+    pn, pa = torch.from_numpy(z["prev_nar"]), torch.from_numpy(z["prev_ar"])
+    eq = lambda a, k: np.testing.assert_array_equal(a.numpy(), z[k])
+    eq(vo.repetition_penalize(lg.clone(), pn, 1.3, 0.0), "rep_nar")
+    eq(vo.repetition_penalize(lg.clone(), pn, 1.2, 0.5), "rep_nar_decay")
+    eq(vo.repetition_penalize(lg[:1].clone(), pa, 1.25, 0.0), "rep_ar")
+    eq(vo.repetition_penalize(lg[:1].clone(), pa, 1.1, 0.25), "rep_ar_decay")
+    # quirk: exactly one previous token and one row is classified NAR -> nothing is penalised
+    out = vo.repetition_penalize(lg[:1].clone(), pa[:1], 1.5, 0.0)
+    eq(out, "rep_ar_one_prev")
+    np.testing.assert_array_equal(out.numpy(), lg[:1].numpy())
+    eq(vo.length_penalize(lg[:1].clone(), 10, 0.5, 1024), "len_pos")
+    eq(vo.length_penalize(lg[:1].clone(), 10, -0.5, 1024), "len_neg")
+    np.testing.assert_array_equal(z["ban"], lg[:, :1024].numpy())  # ban_tokens is a no-op
+    eq(vo.top_k_top_p_filter(lg.clone(), 20, 1.0), "topk")
+    eq(vo.top_k_top_p_filter(lg.clone(), 0, 0.8), "topp")
+    eq(vo.top_k_top_p_filter(lg.clone(), 50, 0.9), "topk_topp")
+    eq(vo.top_n_sigma(lg.clone()), "top_no")
+    eq(vo.min_p_filter(lg.clone(), 0.05), "min_p")
+    pos = [torch.from_numpy(z["cfg_pos_0"]), torch.from_numpy(z["cfg_pos_1"])]
+    neg = [torch.from_numpy(z["cfg_neg_0"]), torch.from_numpy(z["cfg_neg_1"])]
+    r = vo.cfg_combine([p.clone() for p in pos], neg, 3.0, [5, 9], 0.75)
+    assert_close(r[0], z["cfg_out_0"], 1e-6, 1e-6), assert_close(r[1], z["cfg_out_1"], 1e-6, 1e-6)
+    r = vo.cfg_combine([p.clone() for p in pos], neg, 2.0, [5, 9], 0.0)
+    eq(r[0], "cfg_norescale_0"), eq(r[1], "cfg_norescale_1")
+
+
+def _probe(kind, z, phns, proms, langs):
+    o = make_oracle(kind)
+    B = len(phns)
+    plans = [vo.plan_sequence(phns[i], langs[i], proms[i], torch.zeros(0, dtype=torch.int64), 0) for i in range(B)]
+    Tmax = z["pos_ids"].shape[1]
+    for b, p in enumerate(plans):
+        T = int(z[f"seq_len_{b}"])
+        assert p.pos.shape[0] == T
+        np.testing.assert_array_equal(p.pos.numpy(), z["pos_ids"][b, :T])
+        assert (z["pos_ids"][b, T:] == 1).all() and z["mask"][b, :T].all() and not z["mask"][b, T:].any()
+        x = o.embed_sequence(p)
+        rows = z[f"rows_{b}"]
+        np.testing.assert_array_equal(x[rows].numpy(), z[f"emb_rows_{b}"])
+        assert_close(x.double().sum(0), z[f"emb_sum_{b}"], 1e-9, 1e-9)
+    probe = {}
+    logits = o.forward(plans, probe=probe)
+    off = 0
+    for b, p in enumerate(plans):
+        T = int(z[f"seq_len_{b}"])
+        rows = z[f"rows_{b}"]
+        assert_close(probe["layer0"][off:off + T][rows], z[f"layer0_rows_{b}"])
+        assert_close(probe["final"][off:off + T][rows], z[f"final_rows_{b}"])
+        assert_close(logits[b][rows], z[f"logits_rows_{b}"])
+        off += T
+
+
+def test_tiny_forward_probe():
+    z = load_golden("tiny_fwd")
+    phns, proms, langs = golden_inputs(z)
+    _probe("tiny", z, phns, proms, langs)
+    # NAR-style forward at level 3: embedding sums over 3 levels and full logits
+    o = make_oracle("tiny")
+    resps = [torch.from_numpy(z[f"nar_resp_{i}"]) for i in range(2)]
+    plans = [vo.plan_sequence(phns[i], langs[i], proms[i], resps[i], 3) for i in range(2)]
+    for b, p in enumerate(plans):
+        np.testing.assert_array_equal(o.embed_sequence(p).numpy(), z[f"nar_emb_{b}"])
+    logits = o.forward(plans)
+    for b in range(2):
+        assert_close(logits[b], z[f"nar_logits_{b}"])
+
+
+def test_full_forward_probe():
+    z = load_golden("full_b1_fwd")
+    phns, proms, langs = qnt_inputs()
+    assert int(z["seq_len_0"]) == 198  # SURVEY §8c sanity value for the qnt.enc input
+    _probe("full", z, phns, proms, langs)
+
+
+def _ar_nar(kind, name, use_cache=False, **model_kw):
+    z = load_golden(name)
+    phns, proms, langs = golden_inputs(z)
+    o = make_oracle(kind, **model_kw)
+    B = len(phns)
+    kw = {k[3:]: float(v) for k, v in z.items() if k.startswith("kw_") and not k.startswith("kw_nar_")}
+    if "top_k" in kw:
+        kw["top_k"] = int(kw["top_k"])
+    nar_kw = {k[7:]: float(v) for k, v in z.items() if k.startswith("kw_nar_")}
+    codes, last = o.ar(phns, proms, langs, max_duration=int(z["steps"]), temperature=0.0, use_cache=use_cache,
+                       return_logits=True, **kw)
+    for b in range(B):
+        np.testing.assert_array_equal(codes[b].numpy(), z[f"ar_codes_{b}"])
+    if "ar_last_logits" in z:
+        n = z["ar_last_logits"].shape[0]
+        assert_close(torch.stack(last[:n]), z["ar_last_logits"], 5e-4, 5e-4)
+    if "nar_codes_0" in z:
+        full = o.nar(phns, proms, langs, codes, temperature=0.0, **nar_kw)
+        for b in range(B):
+            np.testing.assert_array_equal(full[b].numpy(), z[f"nar_codes_{b}"])
+
+
+def test_tiny_ar_nar_recompute():
+    _ar_nar("tiny", "tiny_ar_nar")
+
+
+def test_tiny_ar_kv_cache_equals_recompute():
+    _ar_nar("tiny", "tiny_ar_nar", use_cache=True)
+
+
+def test_tiny_sampling_processors():
+    _ar_nar("tiny", "tiny_sampling_rep")
+    _ar_nar("tiny", "tiny_sampling_topk")
+    z = load_golden("tiny_sampling_topk")
+    # reference quirk: top-k/top-p leave -inf, default top_no=1.0 then sees std=nan and masks everything
+    assert (z["ar_codes_0"] == 0).all()
+
+
+def test_tiny_stop_token_and_length_penalty():
+    z = load_golden("tiny_sampling_stop")
+    assert len(z["ar_codes_0"]) < int(z["steps"])
+    _ar_nar("tiny", "tiny_sampling_stop", stop_bias=0.6)
+
+
+def test_tiny_cfg():
+    _ar_nar("tiny", "tiny_cfg")
+
+
+def _narlen(kind, name):
+    z = load_golden(name)
+    phns, proms, langs = golden_inputs(z)
+    o = make_oracle(kind)
+    full = o.nar_len(phns, proms, langs, [int(x) for x in z["lens"]], max_steps=int(z["max_steps"]), temperature=0.0)
+    for b in range(len(phns)):
+        np.testing.assert_array_equal(full[b].numpy(), z[f"codes_{b}"])
+
+
+def test_tiny_narlen():
+    _narlen("tiny", "tiny_narlen")
+
+
+def test_full_b1_configs0():
+    """BASELINE.json configs[0]: repo-default model, data/qnt.enc prompt, greedy AR + NAR."""
+    _ar_nar("full", "full_b1")
+
+
+@pytest.mark.slow
+def test_full_b3_ragged():
+    _ar_nar("full", "full_b3", use_cache=True)
+
+
+@pytest.mark.slow
+def test_full_narlen():
+    _narlen("full", "full_narlen")
+
+
+def test_full_bf16_logits_tolerance():
+    """bf16 tolerance: rel-L2 <= 4e-2 against the reference's bf16 logits.  Calibration: the
+    reference's own bf16 run differs from its fp32 run by 2.2e-2 rel-L2 on these rows, so two
+    independent bf16 implementations sit ~sqrt(2) x 2.2e-2 apart."""
+    z = load_golden("full_bf16")
+    phns, proms, langs = qnt_inputs()
+    o = make_oracle("full", dtype=torch.bfloat16)
+    plan = vo.plan_sequence(phns[0], langs[0], proms[0], torch.zeros(0, dtype=torch.int64), 0)
+    lg = o.forward([plan], rows=[16])[0].float()
+    ref = torch.from_numpy(z["ar_logits_last16"])
+    rel = ((lg - ref).norm() / ref.norm()).item()
+    assert rel < 4e-2, rel

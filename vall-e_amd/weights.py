@@ -1,0 +1,124 @@
+"""State-dict layout of the reference model + the seeded synthetic-weight generator.
+
+The key names and shapes are those listed in SURVEY.md §8 row a22 (obtained by
+instantiating the reference: vall_e/models/base.py:390-494 for the embeddings and
+heads, vall_e/models/arch/llama.py:159-162, :486-488, :508-509, :582 for the
+stack).  A weights file written by the reference (``fp32.sft``) therefore loads
+into this implementation by name.
+
+``synth_state_dict`` is the generator both sides of every parity test use: the
+golden-vector script loads its output into the reference model, the GPU tests
+load the same tensors into the HIP path, so the GPU box can regenerate identical
+weights from this repository alone (no checkpoint travels).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+
+from .config import Model
+
+
+def classifier_layout(cfg: Model):
+    """(names, n_tokens) per head -- vall_e/models/base.py:390-411."""
+    n_resp_tokens = cfg.audio_tokens + (1 if cfg.experimental.causal_size > 0 else 0)
+    L = cfg.resp_levels
+    emb_tokens = [n_resp_tokens] + [n_resp_tokens - 1] * (L - 1) + [n_resp_tokens]
+    cls_tokens = [n_resp_tokens] + [n_resp_tokens - 1] * (L - 1) + [n_resp_tokens - 1]
+    names = ["AR:0:0"] + [f"NAR:{i}:{i+1}" for i in range(L - 1)] + ["NAR:0:0"]
+    cls_names = list(names) + ["stt"]
+    cls_tokens = cls_tokens + [cfg.phoneme_tokens]
+    if "len" in cfg.capabilities:
+        cls_tokens += [11]
+        cls_names += ["len"]
+    if cfg.version >= 6:
+        cls_tokens += [cfg.text_tokens]
+        # base.py:411 rebuilds the name list from the embedding names (which the
+        # in-place ``+=`` above has already extended) and appends "text".
+        cls_names = cls_names + ["text"]
+    return names, emb_tokens, cls_names, cls_tokens
+
+
+def state_dict_spec(cfg: Model) -> "OrderedDict[str, tuple]":
+    """Ordered {name: shape} exactly as ``reference_model.state_dict()`` yields it."""
+    d = cfg.dim
+    ff = cfg.dim * cfg.ffn
+    L = cfg.resp_levels
+    _, emb_tokens, _, cls_tokens = classifier_layout(cfg)
+    spec = OrderedDict()
+    spec["sep"] = (d,)
+    spec["dropout_token"] = (d,)
+    spec["text_emb.weight"] = (cfg.phoneme_tokens, d)
+    for i in range(L):
+        spec[f"proms_emb.embeddings.{i}.weight"] = (cfg.audio_tokens, d)
+    for i, n in enumerate(emb_tokens):
+        spec[f"resps_emb.embeddings.{i}.weight"] = (n, d)
+    if cfg.langs > 0:
+        spec["langs_emb.weight"] = (cfg.langs, d)
+    if cfg.tasks > 0:
+        spec["tasks_emb.weight"] = (cfg.tasks, d)
+    if cfg.tones > 0:
+        spec["tones_emb.weight"] = (cfg.tones, d)
+    spec["rvq_l_emb.weight"] = (L, d)
+    spec["len_emb.weight"] = (11, d)
+    spec["raw_text_emb.weight"] = (cfg.text_tokens, d)
+    for l in range(cfg.layers):
+        p = f"model.layers.{l}."
+        spec[p + "self_attn.q_proj.weight"] = (d, d)
+        spec[p + "self_attn.k_proj.weight"] = (d, d)
+        spec[p + "self_attn.v_proj.weight"] = (d, d)
+        spec[p + "self_attn.o_proj.weight"] = (d, d)
+        spec[p + "mlp.gate_proj.weight"] = (ff, d)
+        spec[p + "mlp.up_proj.weight"] = (ff, d)
+        spec[p + "mlp.down_proj.weight"] = (d, ff)
+        spec[p + "input_layernorm.weight"] = (d,)
+        spec[p + "post_attention_layernorm.weight"] = (d,)
+    spec["model.norm.weight"] = (d,)
+    if cfg.experimental.split_classifiers:
+        for k, n in enumerate(cls_tokens):
+            spec[f"classifiers.proj.{k}.weight"] = (n, d)
+            if cfg.experimental.classifiers_bias:
+                spec[f"classifiers.proj.{k}.bias"] = (n,)
+    return spec
+
+
+def _kind(name: str) -> str:
+    if name.endswith("layernorm.weight") or name == "model.norm.weight":
+        return "norm"
+    if name.startswith("classifiers.") and name.endswith(".bias"):
+        return "head_bias"
+    if name.startswith("classifiers."):
+        return "head"
+    if ".self_attn." in name or ".mlp." in name:
+        return "linear"
+    return "embedding"
+
+
+def synth_state_dict(cfg: Model, seed: int = 1234, stop_bias: float | None = None,
+                     linear_std: float = 0.03, head_std: float = 0.05) -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic fp32 CPU weights: tensor ``idx`` (spec order) is drawn from
+    ``torch.Generator().manual_seed(seed + idx)``.
+
+    Scales keep activations O(1) through the stack (so kernel errors are visible
+    in logits) and give greedy decisions a healthy top-2 margin.  ``stop_bias``
+    overrides the AR head's bias for the stop token (bench: a large negative value
+    forces fixed-length generation identically on every implementation).
+    """
+    out = OrderedDict()
+    for idx, (name, shape) in enumerate(state_dict_spec(cfg).items()):
+        g = torch.Generator(device="cpu").manual_seed(seed + idx)
+        x = torch.randn(shape, generator=g, dtype=torch.float32)
+        kind = _kind(name)
+        if kind == "norm":
+            x = 1.0 + 0.1 * x
+        elif kind == "linear":
+            x = linear_std * x
+        elif kind == "head":
+            x = head_std * x
+        elif kind == "head_bias":
+            x = 0.1 * x
+        out[name] = x
+    if stop_bias is not None and "classifiers.proj.0.bias" in out:
+        out["classifiers.proj.0.bias"][cfg.audio_tokens] = stop_bias
+    return out
