@@ -1,0 +1,228 @@
+/*
+ * valle_hip.h -- C ABI of libvalle_hip.so: the MI355X (gfx950) kernels behind the
+ * AR+NAR forward of e-c-k-e-r/vall-e.
+ *
+ * The reference is pure Python/PyTorch: its "FFI" for this path is the set of torch
+ * operators its modules call.  Each entry point below replaces one such call site (cited
+ * as reference file:line, relative to the reference repo root) and is what a maintainer
+ * would bind through ctypes (see INTEGRATION.md for the stubs).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative VALLE_E_* code otherwise;
+ *     valle_last_error() returns a static string describing the last failure of the
+ *     calling thread;
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - `dtype` selects the storage/compute type of activations and weights:
+ *     VALLE_F32 (parity path: fp32 storage, fp32 MFMA accumulate) or VALLE_BF16
+ *     (throughput path: bf16 storage, fp32 accumulate);
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, nothing synchronises;
+ *   - no entry point allocates or frees device memory; workspaces are caller-owned.
+ *
+ * Activation layout: token-packed.  A batch of B utterances with lengths T_b is one
+ * row-major matrix [M = sum T_b][d]; `cu_seqlens` (int32[B+1]) holds the row offsets.
+ * (The reference right-pads to [B][Tmax][d] and masks, models/base.py:112-118, :1204-1225;
+ * under its all-causal masks, base.py:1233, packed and padded give the same rows.)
+ *
+ * Weight layouts (prepared once by the host from the reference's state-dict names):
+ *   w_qkv  [3d][d]   rows = q_proj | k_proj | v_proj (arch/llama.py:159-161); inside every
+ *                    q and k head the 64 rows are re-ordered (0,32,1,33,...,31,63) so the two
+ *                    elements a RoPE rotation mixes (arch/llama.py:48-61) are adjacent;
+ *                    q.k dot products are invariant under this common permutation.
+ *   w_o    [d][d]    o_proj (arch/llama.py:162)
+ *   w_gu   [2f][d]   rows interleaved gate_0, up_0, gate_1, up_1, ... (arch/llama.py:486-487)
+ *   w_down [d][f]    down_proj (arch/llama.py:488)
+ *   emb    [R][d]    all embedding tables + `sep` concatenated row-wise (models/base.py:420-450)
+ */
+#ifndef VALLE_HIP_H
+#define VALLE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VALLE_F32  0
+#define VALLE_BF16 1
+
+#define VALLE_OK            0
+#define VALLE_E_ARG        -1   /* bad argument (shape, alignment, null pointer)            */
+#define VALLE_E_UNSUPPORTED -2  /* valid in the reference, not built here (message says what) */
+#define VALLE_E_HIP        -3   /* a HIP runtime call failed                                 */
+#define VALLE_E_WORKSPACE  -4   /* caller workspace too small                                */
+
+/* GEMM epilogues */
+#define VALLE_EPI_STORE  0      /* C = A.W^T (+ bias)                                          */
+#define VALLE_EPI_RESID  1      /* C = resid + A.W^T                                           */
+#define VALLE_EPI_GEGLU  2      /* C[:, j] = gelu_erf(acc[:, 2j]) * acc[:, 2j+1]  (N/2 columns) */
+#define VALLE_EPI_F32OUT 3      /* C (fp32) = A.W^T + bias, whatever `dtype` is                */
+
+const char* valle_last_error(void);
+int valle_version(void);
+
+/* ---------------------------------------------------------------- operator level ---- */
+
+/* Summed embedding gather.  out[r] = sum_j emb[idx[r][j]] over the non-negative entries of
+ * idx[r][0..7], added in index order in the storage dtype (the reference's Python sum()).
+ * Replaces Base.inputs_to_embeddings + AudioEmbedding.forward + _join
+ * (models/base.py:774-922, :147-175, :101-110): per-level prom/resp tables, text/lang/
+ * rvq-level/len tables and the `sep` rows are all rows of the one concatenated table. */
+int valle_embed_sum(const void* emb, const int32_t* idx, void* out, int rows, int d, int dtype, void* stream);
+
+/* RMSNorm: out = w * cast(x * rsqrt(mean(x^2) + eps)) -- arch/llama.py:64-77 (weight applied
+ * after the down-cast). */
+int valle_rmsnorm(const void* x, const void* w, void* out, int rows, int d, float eps, int dtype, void* stream);
+
+/* C[M][N] = A[M][K] . W[N][K]^T with an epilogue (nn.Linear call sites:
+ * arch/llama.py:307-309, :475, :492; models/base.py:217).  K % 32 == 0.  `bias` (N, same dtype;
+ * fp32 for EPI_F32OUT) and `resid` ([M][ldc]) may be NULL when the epilogue does not use them.
+ * ldc = leading dimension of C (and resid), in elements. */
+int valle_gemm(const void* A, const void* W, const void* bias, const void* resid, void* C,
+               int M, int N, int K, int ldc, int epilogue, int dtype, void* stream);
+
+/* RoPE on the q and k parts of packed qkv rows [M][3d] (in place, pair-interleaved head
+ * layout, see w_qkv) using the fp32 table rope[pos][Dh/2][2] = (cos, sin)
+ * (arch/llama.py:82-132, :48-61), then optionally copies the rotated k and v rows into a
+ * KV cache laid out [slot][H][cache_T][Dh]: row r of utterance b goes to
+ * slot cache_slot[b], position cache_pos0[b] + (r - cu_seqlens[b]).  kcache may be NULL. */
+int valle_rope_kv(void* qkv, const int32_t* pos, const float* rope, const int32_t* cu_seqlens,
+                  int B, int M, int H, int Dh, void* kcache, void* vcache, int cache_T,
+                  const int32_t* cache_slot, const int32_t* cache_pos0, int dtype, void* stream);
+
+/* Causal self-attention over packed qkv rows [M][3d] -> out [M][d]; softmax scale 1/sqrt(Dh).
+ * Replaces SDPA with the additive causal+padding mask (arch/llama.py:448-456, :689-730).
+ * `causal` = 0 gives full (non-causal) attention inside each utterance (noncausal_masks). */
+int valle_attn_prefill(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int M, int max_T,
+                       int H, int Dh, int causal, int dtype, void* stream);
+
+/* One-query-per-utterance attention against the KV cache (the KV-cache restatement of the
+ * reference's full recompute, models/base.py:521 use_cache=False).  q rows come from qkv [B][3d];
+ * utterance b reads ctx_len[b] cached positions of slot cache_slot[b]. */
+int valle_attn_decode(const void* qkv, const void* kcache, const void* vcache, const int32_t* ctx_len,
+                      const int32_t* cache_slot, void* out, int B, int H, int Dh, int cache_T,
+                      int dtype, void* stream);
+
+/* Sampler parameters -- Base.sample's kwargs (models/base.py:1288-1309). */
+typedef struct {
+    float temperature;              /* <= 0: argmax                                          */
+    int   top_k;                    /* <= 0: off                                             */
+    float top_p;                    /* >= 1: off                                             */
+    float min_p;                    /* <= 0: off                                             */
+    float top_no;                   /* <= 0: off; reference default 1.0 (base.py:1307)       */
+    float repetition_penalty;       /* 1.0: off                                              */
+    float repetition_penalty_decay;
+    float length_penalty;           /* 0.0: off; AR rows only                                */
+    int   stop_token;
+    int   rep_pen_passes;           /* 1; 2 reproduces NAR-len's second in-place pass        */
+    uint64_t seed;                  /* Philox seed for temperature > 0                       */
+    uint64_t offset;                /* Philox offset (advance per call)                      */
+} valle_sample_params;
+
+/* Sampler chain on fp32 logits [rows][ld] (first `vocab` columns valid): repetition penalty
+ * (samplers.py:16-50) -> length penalty (:56-61, AR rows) -> min-p (:74-90) -> top-k/top-p
+ * (:93-125) -> /temperature -> top-n-sigma (:164-172) -> argmax or categorical
+ * (base.py:1419-1422) -> score = softmax(processed)[token] (base.py:1425-1428).
+ * Row r belongs to utterance row_item[r]; its previous tokens are prev[prev_off[i] ..
+ * prev_off[i] + prev_len[i]).  nar_mode != 0: row r (row_in_item[r]) is penalised only by
+ * previous tokens at positions < row_in_item[r] (samplers.py:38-39).  AR rows with exactly one
+ * previous token get no penalty (the reference classifies them as NAR, samplers.py:22).
+ * Outputs: ids[rows] (int32), scores[rows] (fp32, may be NULL). */
+int valle_sample(const float* logits, int ld, int vocab, int rows, const int32_t* row_item,
+                 const int32_t* row_in_item, const int32_t* prev, const int32_t* prev_off,
+                 const int32_t* prev_len, int nar_mode, const valle_sample_params* params,
+                 int32_t* ids, float* scores, void* stream);
+
+/* Classifier-free guidance (samplers.py:177-191) on fp32 logits, per utterance i over its
+ * rows [row_off[i], row_off[i+1]): s = neg + (pos - neg) * strength; if rescale > 0,
+ * s *= rescale * std(pos)/std(s) + (1 - rescale) with std the unbiased std over ALL
+ * rows x vocab of that utterance.  Written in place into `pos`. */
+int valle_cfg_combine(float* pos, const float* neg, int ld, int vocab, const int32_t* row_off, int B,
+                      float strength, float rescale, void* stream);
+
+/* NAR-len masking step (models/ar_nar.py:358-365): for utterance i with scores
+ * s[off[i] .. off[i+1]), sets codes[j] = mask_token at the k[i] lowest-score positions
+ * (ties broken by lower index) and writes is_masked[j] = (codes[j] == mask_token).
+ * max_len = the longest utterance (host-side bound, <= 8192). */
+int valle_mask_lowest(const float* scores, int32_t* codes, uint8_t* is_masked, const int32_t* off,
+                      const int32_t* k, int B, int max_len, int mask_token, void* stream);
+
+/* ------------------------------------------------------------------- model level ---- */
+
+typedef struct {
+    int d_model, n_heads, n_layers, d_ff;
+    int dtype;
+    float rms_eps;
+    int max_pos;            /* rows of the rope table */
+} valle_config;
+
+typedef struct {
+    const void *ln1, *w_qkv, *w_o, *ln2, *w_gu, *w_down;
+} valle_layer_weights;
+
+typedef struct valle_model valle_model;
+
+/* Builds a host-side descriptor holding the device pointers (no device allocation, no copy).
+ * heads: n_cls classifier heads (models/base.py:179-231), head k = (w [n_k][d], b [n_k] fp32 or NULL). */
+int valle_model_create(const valle_config* cfg, const void* emb, const float* rope,
+                       const valle_layer_weights* layers_host, const void* final_norm,
+                       int n_cls, const void* const* head_w_host, const float* const* head_b_host,
+                       const int32_t* head_n_host, valle_model** out);
+void valle_model_destroy(valle_model* m);
+
+/* Workspace bytes valle_forward_dense needs for M packed rows and n_out output rows. */
+size_t valle_dense_workspace_bytes(const valle_model* m, int M, int n_out);
+
+/* One full (non-incremental) pass: embedding sums -> n_layers x {RMSNorm, QKV, RoPE, causal
+ * attention, o_proj, RMSNorm, GEGLU MLP} -> final RMSNorm -> classifier `head` on the rows
+ * listed in out_rows (packed row ids) -> fp32 logits [n_out][ld_logits].
+ * = Base.forward (models/base.py:1184-1278) for one homogeneous classifier level.
+ * If kcache != NULL the rotated K and V of every layer are also written to the caches
+ * ([n_layers][slots][H][cache_T][Dh], layer stride cache_layer_stride elements): the AR prefill.
+ * hidden_out (optional, [n_out][d] in dtype) receives the normalised hidden rows. */
+int valle_forward_dense(valle_model* m, const int32_t* emb_idx, const int32_t* pos,
+                        const int32_t* cu_seqlens, int B, int M, int max_T, int causal,
+                        void* kcache, void* vcache, int cache_T, size_t cache_layer_stride,
+                        const int32_t* cache_slot, const int32_t* cache_pos0,
+                        const int32_t* out_rows, int n_out, int head, float* logits, int ld_logits,
+                        void* hidden_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Device-resident AR state (one per batch). All arrays are caller-allocated device memory. */
+typedef struct {
+    int B;
+    int max_steps;              /* capacity of seq (tokens per utterance)                     */
+    int32_t* seq;               /* [B][max_steps] generated tokens (level 0)                  */
+    int32_t* seq_len;           /* [B] tokens generated so far                                */
+    int32_t* ctx_len;           /* [B] cached positions per utterance                         */
+    int32_t* resp_pos0;         /* [B] RoPE position of response token 0 (0 unless prefixed)  */
+    int32_t* cache_slot;        /* [B]                                                        */
+    int32_t* stopped;           /* [B] 1 once the stop token was sampled                      */
+    float*   scores;            /* [B] score of the last sampled token (may be NULL)          */
+    void*    kcache;            /* [n_layers][slots][H][cache_T][Dh]                          */
+    void*    vcache;
+    int      cache_T;
+    size_t   cache_layer_stride;
+    int32_t  resp_emb_row0;     /* row of resps_emb[0][0] in the concatenated table           */
+    int      head;              /* classifier index (AR:0:0 = 0)                              */
+    int      vocab;             /* columns of that head                                       */
+} valle_ar_state;
+
+size_t valle_decode_workspace_bytes(const valle_model* m, int B);
+
+/* n_steps AR decode steps, enqueued back to back on `stream` with no host synchronisation:
+ * each step embeds every utterance's newest token (seq[b][seq_len[b]-1]), runs the stack on
+ * that one row per utterance against the KV cache, applies head `st->head`, samples
+ * (valle_sample semantics, AR mode, prev = seq[b][:seq_len[b]]), appends the token and
+ * updates seq_len / ctx_len / stopped on the device.  = one iteration of the loop at
+ * models/ar_nar.py:748-848 per step, with the recompute replaced by the cache.
+ * logits_out (optional, [n_steps][B][ld_logits] fp32) keeps every step's raw logits.
+ * sp == NULL (n_steps must be 1): the step stops after the head; the caller combines/samples the
+ * logits itself and appends the token (classifier-free-guidance path, ar_nar.py:785-800). */
+int valle_ar_decode(valle_model* m, const valle_ar_state* st, const valle_sample_params* sp,
+                    int n_steps, float* logits_out, int ld_logits,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VALLE_HIP_H */

@@ -1,0 +1,280 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle and the reference's goldens."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_inputs, qnt_inputs, model_cfg, synth_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_model(kind, dtype=torch.float32, **kw):
+    from vall_e_amd.models import get_model
+    m = get_model(model_cfg(kind), training=False)
+    m.load_state_dict(synth_weights(kind, **kw))
+    return m.to("cuda:0", dtype)
+
+
+def oracle(kind, dtype=torch.float32, **kw):
+    import valle_oracle as vo
+    return vo.Oracle(model_cfg(kind), synth_weights(kind, **kw), dtype=dtype)
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+# ------------------------------------------------------------------------------ operators
+def test_embed_and_positions_bit_exact(gpu_device):
+    import valle_oracle as vo
+    from vall_e_amd import _lib as L
+    z = load_golden("tiny_fwd")
+    phns, proms, langs = golden_inputs(z)
+    m = hip_model("tiny")
+    m._prepare()
+    resps = [torch.from_numpy(z[f"nar_resp_{i}"]) for i in range(2)]
+    plan = m.plan(phns, langs, proms, resps, 3)
+    out = torch.empty((plan.M, m.d_model), device=gpu_device)
+    idx = m._i32(plan.idx)
+    L.check(L.load().valle_embed_sum(L.ptr(m._bufs["emb"]), L.ptr(idx), L.ptr(out), plan.M, m.d_model, L.F32, L.stream_ptr()))
+    ref = np.concatenate([z["nar_emb_0"], z["nar_emb_1"]])
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    o = oracle("tiny")
+    want = np.concatenate([vo.plan_sequence(phns[i], langs[i], proms[i], resps[i], 3).pos.numpy() for i in range(2)])
+    np.testing.assert_array_equal(plan.pos, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rmsnorm(gpu_device, dtype):
+    from vall_e_amd import _lib as L
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(37, 1024, generator=g) * 3).to(dtype)
+    w = (1 + 0.1 * torch.randn(1024, generator=g)).to(dtype)
+    xf = x.float()
+    want = w * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(dtype)
+    xd, wd = x.to(gpu_device), w.to(gpu_device)
+    out = torch.empty_like(xd)
+    L.check(L.load().valle_rmsnorm(L.ptr(xd), L.ptr(wd), L.ptr(out), 37, 1024, 1e-6, L.dtype_code(dtype), L.stream_ptr()))
+    tol = 2e-6 if dtype == torch.float32 else 1e-2
+    torch.testing.assert_close(out.cpu().float(), want.float(), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype,epi", [(torch.float32, 0), (torch.bfloat16, 0), (torch.float32, 1), (torch.bfloat16, 2), (torch.float32, 2),
+                                       (torch.bfloat16, 3), (torch.float32, 3)])
+@pytest.mark.parametrize("shape", [(200, 384, 256), (129, 1025, 1024), (16, 1024, 4096)])
+def test_gemm_epilogues(gpu_device, dtype, epi, shape):
+    from vall_e_amd import _lib as L
+    M, N, K = shape
+    if epi == 2 and N % 4:
+        pytest.skip("GEGLU needs N % 4 == 0")
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).to(dtype)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype)
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g).to(dtype)
+    acc = A.double() @ W.double().T
+    ldc = N // 2 if epi == 2 else (N + 7) // 8 * 8
+    if epi == 0:
+        want, out_dtype = acc, dtype
+    elif epi == 1:
+        want, out_dtype = resid.double() + acc, dtype
+    elif epi == 2:
+        want, out_dtype = torch.nn.functional.gelu(acc[:, 0::2]) * acc[:, 1::2], dtype
+    else:
+        want, out_dtype = acc + bias.double(), torch.float32
+    Cd = torch.zeros((M, ldc), dtype=out_dtype, device=gpu_device)
+    Rd = None
+    if epi == 1:
+        Rd = torch.zeros((M, ldc), dtype=dtype, device=gpu_device)
+        Rd[:, :N] = resid.to(gpu_device)
+    Ad, Wd = A.to(gpu_device), W.to(gpu_device)
+    bd = bias.to(gpu_device) if epi == 3 else None
+    L.check(L.load().valle_gemm(L.ptr(Ad), L.ptr(Wd), L.ptr(bd), L.ptr(Rd), L.ptr(Cd), M, N, K, ldc, epi, L.dtype_code(dtype), L.stream_ptr()))
+    got = Cd[:, : want.shape[1]].double().cpu()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert ((got - want).norm() / want.norm()).item() < tol
+    assert (got - want).abs().max().item() < (1e-4 if dtype == torch.float32 else 0.15)
+
+
+def test_sampler_known_answers(gpu_device):
+    """valle_sample / valle_cfg_combine against the reference's own sampler outputs (samplers_kat)."""
+    m = hip_model("tiny")
+    z = load_golden("samplers_kat")
+    lg = torch.from_numpy(z["logits"])
+    pa = torch.from_numpy(z["prev_ar"])
+
+    def run(logits, prev, nar, **kw):
+        rows, V = logits.shape
+        ld = (V + 7) // 8 * 8
+        buf = torch.zeros((rows, ld), device=gpu_device)
+        buf[:, :V] = logits.to(gpu_device)
+        off = np.array([0, rows], dtype=np.int32)
+        sp = m.sample_params(temperature=0.0, **kw)
+        ids, sc = m.sample_rows(buf, V, off, [prev] if prev is not None else None, nar, sp)
+        return ids.cpu().numpy(), sc.cpu().numpy()
+
+    def expect(processed):
+        t = torch.from_numpy(processed)
+        t = torch.where(t >= t.max(-1, keepdim=True).values - t.std(-1, keepdim=True), t, torch.full_like(t, -float("inf")))
+        ids = t.argmax(-1)
+        return ids.numpy(), torch.softmax(t, -1).gather(1, ids[:, None])[:, 0].numpy()
+
+    for key, prev, nar, kw in [
+        ("rep_nar", torch.from_numpy(z["prev_nar"]), 1, dict(repetition_penalty=1.3)),
+        ("rep_nar_decay", torch.from_numpy(z["prev_nar"]), 1, dict(repetition_penalty=1.2, repetition_penalty_decay=0.5)),
+        ("rep_ar", pa, 0, dict(repetition_penalty=1.25)),
+        ("rep_ar_decay", pa, 0, dict(repetition_penalty=1.1, repetition_penalty_decay=0.25)),
+        ("rep_ar_one_prev", pa[:1], 0, dict(repetition_penalty=1.5)),
+    ]:
+        src = lg if nar else lg[:1]
+        ids, sc = run(src, prev, nar, **kw)
+        wid, wsc = expect(z[key])
+        np.testing.assert_array_equal(ids, wid, err_msg=key)
+        np.testing.assert_allclose(sc, wsc, rtol=1e-4, err_msg=key)
+    # no top-n-sigma: top-k / top-p survive to the argmax + score
+    for key, kw in [("topk", dict(top_k=20)), ("topp", dict(top_p=0.8)), ("topk_topp", dict(top_k=50, top_p=0.9)), ("min_p", dict(min_p=0.05))]:
+        ids, sc = run(lg, None, 1, top_no=0.0, **kw)
+        t = torch.from_numpy(z[key])
+        wid = t.argmax(-1)
+        np.testing.assert_array_equal(ids, wid.numpy(), err_msg=key)
+        np.testing.assert_allclose(sc, torch.softmax(t, -1).gather(1, wid[:, None])[:, 0].numpy(), rtol=2e-4, err_msg=key)
+    # the reference quirk: filtered (-inf) logits + default top_no -> everything masked -> token 0
+    ids, _ = run(lg, None, 1, top_k=20)
+    assert (ids == 0).all()
+    # cfg
+    pos = [torch.from_numpy(z["cfg_pos_0"]), torch.from_numpy(z["cfg_pos_1"])]
+    neg = [torch.from_numpy(z["cfg_neg_0"]), torch.from_numpy(z["cfg_neg_1"])]
+    for rescale, names in [(0.75, ("cfg_out_0", "cfg_out_1")), (0.0, ("cfg_norescale_0", "cfg_norescale_1"))]:
+        lens = [5, 9]
+        p = torch.cat([pos[i][-lens[i]:] for i in range(2)]).to(gpu_device).contiguous()
+        n = torch.cat([neg[i][-lens[i]:] for i in range(2)]).to(gpu_device).contiguous()
+        m.cfg_combine(p, n, 1024, np.array([0, 5, 14], dtype=np.int32), 3.0 if rescale else 2.0, rescale)
+        got = p.cpu()
+        want = torch.cat([torch.from_numpy(z[names[i]])[-lens[i]:] for i in range(2)])
+        torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
+
+
+# ---------------------------------------------------------------------------- end to end
+def _probe(kind, name, phns, proms, langs):
+    z = load_golden(name)
+    m = hip_model(kind)
+    B = len(phns)
+    out = m.forward_super(dict(phns_list=phns, lang_list=langs, proms_list=proms,
+                               resps_list=[torch.zeros(0, dtype=torch.int64)] * B), quant_levels=[0] * B)
+    for b in range(B):
+        rows = z[f"rows_{b}"]
+        got = out.logits[b][rows].cpu()
+        torch.testing.assert_close(got, torch.from_numpy(z[f"logits_rows_{b}"]), rtol=5e-4, atol=5e-4)
+
+
+def test_tiny_forward_logits_fp32(gpu_device):
+    z = load_golden("tiny_fwd")
+    _probe("tiny", "tiny_fwd", *golden_inputs(z))
+
+
+def test_full_forward_logits_fp32(gpu_device):
+    _probe("full", "full_b1_fwd", *qnt_inputs())
+
+
+def _ar_nar(kind, name, **model_kw):
+    z = load_golden(name)
+    phns, proms, langs = golden_inputs(z)
+    m = hip_model(kind, **model_kw)
+    B = len(phns)
+    kw = {k[3:]: float(v) for k, v in z.items() if k.startswith("kw_") and not k.startswith("kw_nar_")}
+    if "top_k" in kw:
+        kw["top_k"] = int(kw["top_k"])
+    nar_kw = {k[7:]: float(v) for k, v in z.items() if k.startswith("kw_nar_")}
+    codes, logits = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs,
+                      max_duration=int(z["steps"]), temperature=0.0, return_logits=True, step_chunk=5, **kw)
+    for b in range(B):
+        np.testing.assert_array_equal(codes[b].cpu().numpy(), z[f"ar_codes_{b}"], err_msg=f"AR codes of utterance {b}")
+        assert codes[b].dtype == torch.int64
+    if "ar_last_logits" in z:
+        n = min(z["ar_last_logits"].shape[0], len(logits))
+        got = torch.stack([l.cpu() for l in logits[:n]])
+        torch.testing.assert_close(got, torch.from_numpy(z["ar_last_logits"][:n]), rtol=1e-3, atol=1e-3)
+    if "nar_codes_0" in z:
+        full = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs,
+                 resps_list=[c.clone() for c in codes], temperature=0.0, **nar_kw)
+        for b in range(B):
+            np.testing.assert_array_equal(full[b].cpu().numpy(), z[f"nar_codes_{b}"], err_msg=f"NAR codes of utterance {b}")
+
+
+def test_tiny_ar_nar_codes_identical(gpu_device):
+    _ar_nar("tiny", "tiny_ar_nar")
+
+
+def test_tiny_sampling_processors(gpu_device):
+    _ar_nar("tiny", "tiny_sampling_rep")
+    _ar_nar("tiny", "tiny_sampling_topk")
+
+
+def test_tiny_stop_token_and_length_penalty(gpu_device):
+    _ar_nar("tiny", "tiny_sampling_stop", stop_bias=0.6)
+
+
+def test_tiny_cfg(gpu_device):
+    _ar_nar("tiny", "tiny_cfg")
+
+
+def test_full_b1_configs0_codes_identical(gpu_device):
+    """BASELINE.json configs[0] on the HIP fp32 path: greedy AR + NAR codes == the reference's."""
+    _ar_nar("full", "full_b1")
+
+
+def test_full_b3_ragged_codes_identical(gpu_device):
+    _ar_nar("full", "full_b3")
+
+
+def _narlen(kind, name):
+    z = load_golden(name)
+    phns, proms, langs = golden_inputs(z)
+    m = hip_model(kind)
+    B = len(phns)
+    full = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs,
+             len_list=[int(x) for x in z["lens"]], max_steps=int(z["max_steps"]), temperature=0.0)
+    for b in range(B):
+        np.testing.assert_array_equal(full[b].cpu().numpy(), z[f"codes_{b}"])
+
+
+def test_tiny_narlen_codes_identical(gpu_device):
+    _narlen("tiny", "tiny_narlen")
+
+
+def test_full_narlen_codes_identical(gpu_device):
+    _narlen("full", "full_narlen")
+
+
+def test_full_bf16_logits_within_tolerance(gpu_device):
+    """bf16 tolerance (stated): rel-L2 <= 4e-2 against the reference's bf16 logits; the reference's
+    own bf16 run sits 2.2e-2 from its fp32 run on these rows (see test_oracle_vs_golden)."""
+    z = load_golden("full_bf16")
+    phns, proms, langs = qnt_inputs()
+    m = hip_model("full", torch.bfloat16)
+    out = m.forward_super(dict(phns_list=phns, lang_list=langs, proms_list=proms,
+                               resps_list=[torch.zeros(0, dtype=torch.int64)]), quant_levels=[0])
+    assert rel_l2(out.logits[0][-16:], torch.from_numpy(z["ar_logits_last16"])) < 4e-2
+    r = torch.from_numpy(z["nar_resp"])
+    out = m.forward_super(dict(phns_list=phns, lang_list=langs, proms_list=proms, resps_list=[r]), quant_levels=[2])
+    assert rel_l2(out.logits[0][-24:], torch.from_numpy(z["nar_logits"])) < 4e-2
+
+
+def test_bf16_decode_matches_dense_recompute(gpu_device):
+    """KV-cache decode (fused bf16 kernels) vs a dense recompute of the same sequence on the same
+    bf16 path: last-row logits agree to bf16 rounding, and to the oracle's bf16 run within 4e-2."""
+    phns, proms, langs = qnt_inputs()
+    m = hip_model("full", torch.bfloat16)
+    codes, logits = m(task_list=["tts"], phns_list=phns, proms_list=proms, lang_list=langs, max_duration=12,
+                      temperature=0.0, return_logits=True, step_chunk=4)
+    seq = codes[0]
+    dense = m.forward_super(dict(phns_list=phns, lang_list=langs, proms_list=proms, resps_list=[seq[:11]]), quant_levels=[0])
+    assert rel_l2(logits[11][0], dense.logits[0][-1]) < 2e-2
+    o = oracle("full", torch.bfloat16)
+    import valle_oracle as vo
+    plan = vo.plan_sequence(phns[0], langs[0], proms[0], seq[:11].cpu(), 0)
+    want = o.forward([plan], rows=[1])[0][0].float()
+    assert rel_l2(logits[11][0], want) < 4e-2

@@ -1,0 +1,109 @@
+"""CPU-only checks of the host side: sequence planning vs the oracle, C-ABI symbols, error paths."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, golden_inputs, model_cfg, synth_weights
+import valle_oracle as vo
+
+
+def host_model(kind="tiny"):
+    from vall_e_amd.models import get_model
+    m = get_model(model_cfg(kind), training=False)
+    m.load_state_dict(synth_weights(kind))
+    return m
+
+
+def table(m):
+    sd = m._sd
+    return torch.cat([sd[k].reshape(-1, m.d_model) for _, k in m._table_order])
+
+
+@pytest.mark.parametrize("q,timestep", [(0, False), (1, False), (3, False), (7, False), (0, True)])
+def test_plan_matches_oracle_embeddings_and_positions(q, timestep):
+    z = load_golden("tiny_fwd")
+    phns, proms, langs = golden_inputs(z)
+    m = host_model()
+    o = vo.Oracle(model_cfg("tiny"), synth_weights("tiny"))
+    g = torch.Generator().manual_seed(q)
+    resps = [torch.randint(0, 1024, (5 + 3 * i, max(q, 1)), generator=g) for i in range(2)]
+    if q == 0:
+        resps = [r[:, 0] for r in resps]
+    plan = m.plan(phns, langs, proms, resps, q, timestep=timestep)
+    E = table(m)
+    off = 0
+    for i in range(2):
+        p = vo.plan_sequence(phns[i], langs[i], proms[i], resps[i], q, timestep=timestep)
+        want = o.embed_sequence(p)
+        T = want.shape[0]
+        idx = torch.from_numpy(plan.idx[off:off + T]).long()
+        got = torch.zeros(T, m.d_model)
+        started = torch.zeros(T, dtype=torch.bool)
+        for j in range(8):
+            sel = idx[:, j] >= 0
+            got[sel] = torch.where(started[sel, None], got[sel] + E[idx[sel, j]], E[idx[sel, j]])
+            started |= sel
+        np.testing.assert_array_equal(got.numpy(), want.numpy())
+        np.testing.assert_array_equal(plan.pos[off:off + T], p.pos.numpy())
+        assert plan.lens[i] == T and m.cls_names[plan.head] == p.head
+        off += T
+    assert plan.M == off and plan.cu[-1] == off
+
+
+def test_null_cfg_plan_has_no_prompt():
+    m = host_model()
+    plan = m.plan([torch.tensor([1, 2])], [torch.tensor([0])], None, [torch.arange(9)], 0)
+    assert plan.lens == [2 + 1 + 1 + 9 + 3]      # phn, lang, quant_level, resp + 3 seps (SURVEY: R + 7)
+    assert plan.pos.tolist() == [0, 1, 2, 0, 1, 0, 1] + list(range(9))
+
+
+def test_header_symbols_are_exported_and_typed():
+    from vall_e_amd import _lib as L
+    lib = L.load()
+    header = (ROOT / "include" / "valle_hip.h").read_text()
+    declared = set(re.findall(r"\b(valle_[a-z0-9_]+)\s*\(", header))
+    declared -= {"valle_model"}
+    assert declared, "no declarations found"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/valle_hip.h but not exported"
+        assert name in L.SIGNATURES, f"{name} has no ctypes signature"
+    assert lib.valle_version() == 1
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    from vall_e_amd import _lib as L
+    lib = L.load()
+    rc = lib.valle_embed_sum(None, None, None, 4, 1024, L.F32, None)
+    assert rc == -1 and b"null pointer" in lib.valle_last_error()
+    rc = lib.valle_gemm(C.c_void_p(16), C.c_void_p(16), None, None, C.c_void_p(16), 4, 8, 100, 8, 0, L.F32, None)
+    assert rc == -1 and b"multiple of 32" in lib.valle_last_error()
+    with pytest.raises(L.ValleHipError):
+        L.check(rc)
+
+
+def test_product_path_refuses_cpu():
+    from vall_e_amd import _lib as L
+    m = host_model()
+    with pytest.raises(L.ValleHipError, match="no CPU fallback"):
+        m(task_list=["tts"], phns_list=[torch.tensor([1, 5, 2])], proms_list=[torch.zeros(4, 8, dtype=torch.int16)],
+          lang_list=[torch.tensor([0])], max_duration=2, temperature=0.0)
+
+
+def test_unsupported_options_fail_loudly():
+    m = host_model()
+    with pytest.raises(NotImplementedError):
+        m.sample_params(beam_width=4)
+    with pytest.raises(NotImplementedError):
+        m.sample_params(temperature=1.0, min_temperature=0.5)
+    with pytest.raises(NotImplementedError):
+        m(task_list=["stt"], phns_list=None, resps_list=[torch.zeros(3, 8)])
+
+
+def test_state_dict_spec_matches_reference_names():
+    spec = host_model("full").state_dict_spec()
+    assert sum(int(np.prod(s)) for s in spec.values()) == 237_968_641      # parameters as instantiated
+    assert spec["resps_emb.embeddings.0.weight"] == (1025, 1024) and spec["classifiers.proj.9.weight"] == (256, 1024)

@@ -1,0 +1,113 @@
+// Shared device/host helpers for libvalle_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include "../../include/valle_hip.h"
+
+typedef __bf16 bf16;
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WAVE 64
+
+// ---- host-side error plumbing -------------------------------------------------------
+void valle_set_error(const char* fmt, ...);
+
+#define VALLE_REQUIRE(cond, code, ...)            \
+    do {                                          \
+        if (!(cond)) {                            \
+            valle_set_error(__VA_ARGS__);         \
+            return (code);                        \
+        }                                         \
+    } while (0)
+
+#define VALLE_HIP_CHECK(expr)                                                              \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            valle_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return VALLE_E_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+#define VALLE_LAUNCH_CHECK() VALLE_HIP_CHECK(hipGetLastError())
+
+// ---- device helpers -----------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact erf GELU (transformers ACT2FN["gelu"], reference models/base.py:479)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+static inline size_t dtype_size(int dtype) { return dtype == VALLE_BF16 ? 2 : 4; }
+
+// ---- internal launchers shared between translation units ------------------------------
+struct valle_model {
+    valle_config cfg;
+    const void* emb;
+    const float* rope;
+    valle_layer_weights* layers;
+    const void* final_norm;
+    int n_cls;
+    const void** head_w;
+    const float** head_b;
+    int32_t* head_n;
+};
+
+struct SampleArgs {
+    const float* logits; int ld, vocab;
+    const int32_t* row_item; const int32_t* row_in_item;
+    const int32_t* prev; const int32_t* prev_off; const int32_t* prev_len;
+    int nar_mode;
+    valle_sample_params p;
+    int32_t* ids; float* scores;
+    // optional fused AR bookkeeping (valle_ar_decode): row == utterance
+    int32_t* seq; int seq_cap; int32_t* seq_len; int32_t* ctx_len; int32_t* stopped;
+    int prev_is_seq;            // prev tokens of row i = seq[i*seq_cap .. + seq_len[i])
+    uint64_t step;              // added to the Philox offset
+};
+int valle_sample_launch(const SampleArgs& a, int rows, hipStream_t s);
+
+// decode-path launcher (gemm.hip)
+#define DEC_EPI_QKV 10
+struct DecArgs {
+    const bf16* x; const bf16* norm_w; float eps;
+    const bf16* W; const float* bias; const bf16* resid;
+    void* out; int ldo;
+    int B, N, K;
+    // QKV epilogue: RoPE + KV-cache append
+    const float* rope; const int32_t* pos; const int32_t* ctx_len; const int32_t* slot;
+    bf16* kc; bf16* vc; int cache_T; int H; int d;
+};
+int valle_dec_linear_bf16(const DecArgs& a, int epilogue, hipStream_t s);
+
+// attention launchers (ops_basic.hip)
+extern "C" int valle_attn_prefill_rowwise(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int M,
+                                          int H, int Dh, int causal, int dtype, void* stream);
+int valle_attn_decode_launch(const void* qkv, const void* kcache, const void* vcache, const int32_t* ctx_len,
+                             const int32_t* cache_slot, void* out, int B, int H, int Dh, int cache_T,
+                             int ctx_extra, int dtype, void* stream);

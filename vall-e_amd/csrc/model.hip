@@ -1,0 +1,249 @@
+// Model-level orchestration: one dense pass (Base.forward, models/base.py:1184-1278) and the
+// KV-cache AR decode loop (models/ar_nar.py:748-848).  Host code only enqueues kernels.
+#include "common.h"
+#include <stdlib.h>
+
+extern "C" int valle_attn_prefill(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int M, int max_T,
+                                  int H, int Dh, int causal, int dtype, void* stream) {
+    (void)max_T;
+    return valle_attn_prefill_rowwise(qkv, out, cu_seqlens, B, M, H, Dh, causal, dtype, stream);
+}
+
+extern "C" int valle_model_create(const valle_config* cfg, const void* emb, const float* rope,
+                                  const valle_layer_weights* layers_host, const void* final_norm,
+                                  int n_cls, const void* const* head_w_host, const float* const* head_b_host,
+                                  const int32_t* head_n_host, valle_model** out) {
+    VALLE_REQUIRE(cfg && emb && rope && layers_host && final_norm && out, VALLE_E_ARG, "valle_model_create: null pointer");
+    VALLE_REQUIRE(cfg->n_heads > 0 && cfg->d_model % cfg->n_heads == 0 && cfg->d_model / cfg->n_heads == 64,
+                  VALLE_E_UNSUPPORTED, "valle_model_create: head_dim must be 64 (d_model %d, heads %d)", cfg->d_model, cfg->n_heads);
+    VALLE_REQUIRE(cfg->d_model % 32 == 0 && cfg->d_ff % 32 == 0, VALLE_E_ARG, "valle_model_create: d_model/d_ff must be multiples of 32");
+    VALLE_REQUIRE(cfg->dtype == VALLE_F32 || cfg->dtype == VALLE_BF16, VALLE_E_ARG, "valle_model_create: unknown dtype %d", cfg->dtype);
+    valle_model* m = (valle_model*)calloc(1, sizeof(valle_model));
+    VALLE_REQUIRE(m, VALLE_E_ARG, "valle_model_create: out of host memory");
+    m->cfg = *cfg;
+    m->emb = emb; m->rope = rope; m->final_norm = final_norm; m->n_cls = n_cls;
+    m->layers = (valle_layer_weights*)malloc(sizeof(valle_layer_weights) * cfg->n_layers);
+    memcpy(m->layers, layers_host, sizeof(valle_layer_weights) * cfg->n_layers);
+    m->head_w = (const void**)malloc(sizeof(void*) * (n_cls > 0 ? n_cls : 1));
+    m->head_b = (const float**)malloc(sizeof(float*) * (n_cls > 0 ? n_cls : 1));
+    m->head_n = (int32_t*)malloc(sizeof(int32_t) * (n_cls > 0 ? n_cls : 1));
+    for (int k = 0; k < n_cls; ++k) {
+        m->head_w[k] = head_w_host[k];
+        m->head_b[k] = head_b_host ? head_b_host[k] : nullptr;
+        m->head_n[k] = head_n_host[k];
+    }
+    *out = m;
+    return VALLE_OK;
+}
+
+extern "C" void valle_model_destroy(valle_model* m) {
+    if (!m) return;
+    free(m->layers); free((void*)m->head_w); free((void*)m->head_b); free(m->head_n); free(m);
+}
+
+// ------------------------------------------------------------------ small helpers
+template <typename T>
+__global__ __launch_bounds__(128) void gather_rows_kernel(const T* __restrict__ x, const int32_t* __restrict__ rows,
+                                                          T* __restrict__ out, int d) {
+    constexpr int VEC = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    const int r = blockIdx.x, src = rows[r];
+    for (int c = threadIdx.x * VEC; c < d; c += 128 * VEC)
+        *reinterpret_cast<vec_t*>(out + (size_t)r * d + c) = *reinterpret_cast<const vec_t*>(x + (size_t)src * d + c);
+}
+
+// decode step prologue: embed each utterance's newest token, derive its RoPE position
+template <typename T>
+__global__ __launch_bounds__(128) void dec_prepare_kernel(const T* __restrict__ emb, int emb_row0,
+                                                          const int32_t* __restrict__ seq, int seq_cap,
+                                                          const int32_t* __restrict__ seq_len,
+                                                          const int32_t* __restrict__ resp_pos0,
+                                                          T* __restrict__ x, int32_t* __restrict__ pos,
+                                                          int32_t* __restrict__ cu, int d, int B) {
+    constexpr int VEC = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    const int b = blockIdx.x;
+    const int n = seq_len[b];
+    const int tok = seq[(size_t)b * seq_cap + (n - 1)];
+    if (threadIdx.x == 0) {
+        pos[b] = (resp_pos0 ? resp_pos0[b] : 0) + n - 1;
+        cu[b] = b;
+        if (b == B - 1) cu[B] = B;
+    }
+    const T* src = emb + (size_t)(emb_row0 + tok) * d;
+    for (int c = threadIdx.x * VEC; c < d; c += 128 * VEC)
+        *reinterpret_cast<vec_t*>(x + (size_t)b * d + c) = *reinterpret_cast<const vec_t*>(src + c);
+}
+
+struct Carver {
+    char* p; size_t left; bool ok;
+    Carver(void* base, size_t n) : p((char*)base), left(n), ok(true) {}
+    void* take(size_t bytes) {
+        bytes = align_up(bytes, 256);
+        if (bytes > left) { ok = false; return nullptr; }
+        void* r = p; p += bytes; left -= bytes; return r;
+    }
+};
+
+extern "C" size_t valle_dense_workspace_bytes(const valle_model* m, int M, int n_out) {
+    const size_t es = dtype_size(m->cfg.dtype), d = m->cfg.d_model, f = m->cfg.d_ff;
+    size_t t = 0;
+    t += align_up((size_t)M * d * es, 256) * 2;        // x, h
+    t += align_up((size_t)M * 3 * d * es, 256);        // qkv
+    t += align_up((size_t)M * f * es, 256);            // ff
+    t += align_up((size_t)(n_out > 0 ? n_out : 1) * d * es, 256) * 2;  // selected rows (raw, normed)
+    return t;
+}
+
+extern "C" int valle_forward_dense(valle_model* m, const int32_t* emb_idx, const int32_t* pos,
+                                   const int32_t* cu_seqlens, int B, int M, int max_T, int causal,
+                                   void* kcache, void* vcache, int cache_T, size_t cache_layer_stride,
+                                   const int32_t* cache_slot, const int32_t* cache_pos0,
+                                   const int32_t* out_rows, int n_out, int head, float* logits, int ld_logits,
+                                   void* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
+    VALLE_REQUIRE(m && emb_idx && pos && cu_seqlens && workspace, VALLE_E_ARG, "valle_forward_dense: null pointer");
+    VALLE_REQUIRE(B > 0 && M > 0, VALLE_E_ARG, "valle_forward_dense: empty batch (B=%d, M=%d)", B, M);
+    VALLE_REQUIRE(n_out == 0 || out_rows, VALLE_E_ARG, "valle_forward_dense: out_rows missing");
+    VALLE_REQUIRE(logits == nullptr || (head >= 0 && head < m->n_cls && ld_logits >= m->head_n[head]), VALLE_E_ARG,
+                  "valle_forward_dense: bad head %d / ld_logits %d", head, ld_logits);
+    const valle_config& c = m->cfg;
+    const int d = c.d_model, f = c.d_ff, H = c.n_heads, Dh = d / H, dt = c.dtype;
+    const size_t es = dtype_size(dt);
+    Carver ws(workspace, workspace_bytes);
+    void* x = ws.take((size_t)M * d * es);
+    void* h = ws.take((size_t)M * d * es);
+    void* qkv = ws.take((size_t)M * 3 * d * es);
+    void* ff = ws.take((size_t)M * f * es);
+    void* sel = ws.take((size_t)(n_out > 0 ? n_out : 1) * d * es);
+    void* seln = ws.take((size_t)(n_out > 0 ? n_out : 1) * d * es);
+    VALLE_REQUIRE(ws.ok, VALLE_E_WORKSPACE, "valle_forward_dense: workspace %zu B too small (need %zu)", workspace_bytes,
+                  valle_dense_workspace_bytes(m, M, n_out));
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+#define RUN(call) do { rc = (call); if (rc != VALLE_OK) return rc; } while (0)
+    RUN(valle_embed_sum(m->emb, emb_idx, x, M, d, dt, s));
+    for (int l = 0; l < c.n_layers; ++l) {
+        const valle_layer_weights& w = m->layers[l];
+        RUN(valle_rmsnorm(x, w.ln1, h, M, d, c.rms_eps, dt, s));
+        RUN(valle_gemm(h, w.w_qkv, nullptr, nullptr, qkv, M, 3 * d, d, 3 * d, VALLE_EPI_STORE, dt, s));
+        void* kc = kcache ? (char*)kcache + (size_t)l * cache_layer_stride * es : nullptr;
+        void* vc = vcache ? (char*)vcache + (size_t)l * cache_layer_stride * es : nullptr;
+        RUN(valle_rope_kv(qkv, pos, m->rope, cu_seqlens, B, M, H, Dh, kc, vc, cache_T, cache_slot, cache_pos0, dt, s));
+        RUN(valle_attn_prefill(qkv, h, cu_seqlens, B, M, max_T, H, Dh, causal, dt, s));
+        RUN(valle_gemm(h, w.w_o, nullptr, x, x, M, d, d, d, VALLE_EPI_RESID, dt, s));
+        RUN(valle_rmsnorm(x, w.ln2, h, M, d, c.rms_eps, dt, s));
+        RUN(valle_gemm(h, w.w_gu, nullptr, nullptr, ff, M, 2 * f, d, f, VALLE_EPI_GEGLU, dt, s));
+        RUN(valle_gemm(ff, w.w_down, nullptr, x, x, M, d, f, d, VALLE_EPI_RESID, dt, s));
+    }
+    if (n_out > 0) {
+        if (dt == VALLE_BF16) gather_rows_kernel<bf16><<<n_out, 128, 0, s>>>((const bf16*)x, out_rows, (bf16*)sel, d);
+        else gather_rows_kernel<float><<<n_out, 128, 0, s>>>((const float*)x, out_rows, (float*)sel, d);
+        VALLE_LAUNCH_CHECK();
+        void* dst = hidden_out ? hidden_out : seln;
+        RUN(valle_rmsnorm(sel, m->final_norm, dst, n_out, d, c.rms_eps, dt, s));
+        if (logits)
+            RUN(valle_gemm(dst, m->head_w[head], m->head_b[head], nullptr, logits, n_out, m->head_n[head], d, ld_logits,
+                           VALLE_EPI_F32OUT, dt, s));
+    }
+    return VALLE_OK;
+}
+
+extern "C" size_t valle_decode_workspace_bytes(const valle_model* m, int B) {
+    const size_t es = dtype_size(m->cfg.dtype), d = m->cfg.d_model, f = m->cfg.d_ff;
+    size_t t = 0;
+    t += align_up((size_t)B * d * es, 256) * 3;        // x, h, att
+    t += align_up((size_t)B * 3 * d * es, 256);        // qkv
+    t += align_up((size_t)B * f * es, 256);            // ff
+    t += align_up((size_t)B * 2048 * sizeof(float), 256);  // logits
+    t += align_up((size_t)(B + 1) * sizeof(int32_t), 256) * 2 + align_up((size_t)B * sizeof(int32_t), 256);
+    return t;
+}
+
+extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const valle_sample_params* sp,
+                               int n_steps, float* logits_out, int ld_logits,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    VALLE_REQUIRE(m && st && workspace, VALLE_E_ARG, "valle_ar_decode: null pointer");
+    VALLE_REQUIRE(sp != nullptr || n_steps == 1, VALLE_E_ARG, "valle_ar_decode: without sampler params only one step can run");
+    VALLE_REQUIRE(st->B > 0 && st->seq && st->seq_len && st->ctx_len && st->stopped && st->kcache && st->vcache,
+                  VALLE_E_ARG, "valle_ar_decode: incomplete state");
+    VALLE_REQUIRE(st->head >= 0 && st->head < m->n_cls && st->vocab == m->head_n[st->head] && st->vocab <= 2048,
+                  VALLE_E_ARG, "valle_ar_decode: bad head/vocab");
+    VALLE_REQUIRE(logits_out == nullptr || ld_logits >= st->vocab, VALLE_E_ARG, "valle_ar_decode: ld_logits too small");
+    const valle_config& c = m->cfg;
+    const int d = c.d_model, f = c.d_ff, H = c.n_heads, Dh = d / H, dt = c.dtype, B = st->B;
+    const size_t es = dtype_size(dt);
+    Carver ws(workspace, workspace_bytes);
+    void* x = ws.take((size_t)B * d * es);
+    void* h = ws.take((size_t)B * d * es);
+    void* att = ws.take((size_t)B * d * es);
+    void* qkv = ws.take((size_t)B * 3 * d * es);
+    void* ff = ws.take((size_t)B * f * es);
+    float* lg_ws = (float*)ws.take((size_t)B * 2048 * sizeof(float));
+    int32_t* pos = (int32_t*)ws.take((size_t)(B + 1) * sizeof(int32_t));
+    int32_t* cu = (int32_t*)ws.take((size_t)(B + 1) * sizeof(int32_t));
+    VALLE_REQUIRE(ws.ok, VALLE_E_WORKSPACE, "valle_ar_decode: workspace %zu B too small (need %zu)", workspace_bytes,
+                  valle_decode_workspace_bytes(m, B));
+    hipStream_t s = (hipStream_t)stream;
+    const bool fused = (dt == VALLE_BF16) && B <= 32 && (d == 256 || d == 1024) && (f == 256 || f == 1024 || f == 4096);
+    int rc;
+    for (int step = 0; step < n_steps; ++step) {
+        float* lg = logits_out ? logits_out + (size_t)step * B * ld_logits : lg_ws;
+        const int ldl = logits_out ? ld_logits : 2048;
+        if (dt == VALLE_BF16)
+            dec_prepare_kernel<bf16><<<B, 128, 0, s>>>((const bf16*)m->emb, st->resp_emb_row0, st->seq, st->max_steps, st->seq_len, st->resp_pos0, (bf16*)x, pos, cu, d, B);
+        else
+            dec_prepare_kernel<float><<<B, 128, 0, s>>>((const float*)m->emb, st->resp_emb_row0, st->seq, st->max_steps, st->seq_len, st->resp_pos0, (float*)x, pos, cu, d, B);
+        VALLE_LAUNCH_CHECK();
+        for (int l = 0; l < c.n_layers; ++l) {
+            const valle_layer_weights& w = m->layers[l];
+            void* kc = (char*)st->kcache + (size_t)l * st->cache_layer_stride * es;
+            void* vc = (char*)st->vcache + (size_t)l * st->cache_layer_stride * es;
+            if (fused) {
+                DecArgs a{};
+                a.x = (const bf16*)x; a.norm_w = (const bf16*)w.ln1; a.eps = c.rms_eps; a.W = (const bf16*)w.w_qkv;
+                a.out = qkv; a.ldo = 3 * d; a.B = B; a.N = 3 * d; a.K = d;
+                a.rope = m->rope; a.pos = pos; a.ctx_len = st->ctx_len; a.slot = st->cache_slot;
+                a.kc = (bf16*)kc; a.vc = (bf16*)vc; a.cache_T = st->cache_T; a.H = H; a.d = d;
+                RUN(valle_dec_linear_bf16(a, DEC_EPI_QKV, s));
+                RUN(valle_attn_decode_launch(qkv, kc, vc, st->ctx_len, st->cache_slot, att, B, H, Dh, st->cache_T, 1, dt, s));
+                DecArgs o{};
+                o.x = (const bf16*)att; o.W = (const bf16*)w.w_o; o.resid = (const bf16*)x; o.out = x; o.ldo = d; o.B = B; o.N = d; o.K = d;
+                RUN(valle_dec_linear_bf16(o, VALLE_EPI_RESID, s));
+                DecArgs g{};
+                g.x = (const bf16*)x; g.norm_w = (const bf16*)w.ln2; g.eps = c.rms_eps; g.W = (const bf16*)w.w_gu;
+                g.out = ff; g.ldo = f; g.B = B; g.N = 2 * f; g.K = d;
+                RUN(valle_dec_linear_bf16(g, VALLE_EPI_GEGLU, s));
+                DecArgs dn{};
+                dn.x = (const bf16*)ff; dn.W = (const bf16*)w.w_down; dn.resid = (const bf16*)x; dn.out = x; dn.ldo = d; dn.B = B; dn.N = d; dn.K = f;
+                RUN(valle_dec_linear_bf16(dn, VALLE_EPI_RESID, s));
+            } else {
+                RUN(valle_rmsnorm(x, w.ln1, h, B, d, c.rms_eps, dt, s));
+                RUN(valle_gemm(h, w.w_qkv, nullptr, nullptr, qkv, B, 3 * d, d, 3 * d, VALLE_EPI_STORE, dt, s));
+                RUN(valle_rope_kv(qkv, pos, m->rope, cu, B, B, H, Dh, kc, vc, st->cache_T, st->cache_slot, st->ctx_len, dt, s));
+                RUN(valle_attn_decode_launch(qkv, kc, vc, st->ctx_len, st->cache_slot, att, B, H, Dh, st->cache_T, 1, dt, s));
+                RUN(valle_gemm(att, w.w_o, nullptr, x, x, B, d, d, d, VALLE_EPI_RESID, dt, s));
+                RUN(valle_rmsnorm(x, w.ln2, h, B, d, c.rms_eps, dt, s));
+                RUN(valle_gemm(h, w.w_gu, nullptr, nullptr, ff, B, 2 * f, d, f, VALLE_EPI_GEGLU, dt, s));
+                RUN(valle_gemm(ff, w.w_down, nullptr, x, x, B, d, f, d, VALLE_EPI_RESID, dt, s));
+            }
+        }
+        if (fused) {
+            DecArgs hd{};
+            hd.x = (const bf16*)x; hd.norm_w = (const bf16*)m->final_norm; hd.eps = c.rms_eps; hd.W = (const bf16*)m->head_w[st->head];
+            hd.bias = m->head_b[st->head]; hd.out = lg; hd.ldo = ldl; hd.B = B; hd.N = st->vocab; hd.K = d;
+            RUN(valle_dec_linear_bf16(hd, VALLE_EPI_F32OUT, s));
+        } else {
+            RUN(valle_rmsnorm(x, m->final_norm, h, B, d, c.rms_eps, dt, s));
+            RUN(valle_gemm(h, m->head_w[st->head], m->head_b[st->head], nullptr, lg, B, st->vocab, d, ldl, VALLE_EPI_F32OUT, dt, s));
+        }
+        if (sp == nullptr) break;   // logits only: the caller samples and appends (CFG path)
+        SampleArgs sa{};
+        sa.logits = lg; sa.ld = ldl; sa.vocab = st->vocab; sa.nar_mode = 0; sa.p = *sp;
+        sa.ids = pos;  // scratch: the token also lands in seq
+        sa.scores = st->scores;
+        sa.seq = st->seq; sa.seq_cap = st->max_steps; sa.seq_len = st->seq_len; sa.ctx_len = st->ctx_len; sa.stopped = st->stopped;
+        sa.prev_is_seq = 1; sa.step = (uint64_t)step;
+        RUN(valle_sample_launch(sa, B, s));
+    }
+    return VALLE_OK;
+}

@@ -1,0 +1,394 @@
+// Sampler chain, classifier-free guidance and NAR-len masking (gfx950).
+//   sample        models/base.py:1280-1430 + samplers.py:16-172
+//   cfg_combine   samplers.py:177-191
+//   mask_lowest   models/ar_nar.py:358-365
+#include "common.h"
+
+#define SAMP_MAXV 2048
+#define SAMP_THREADS 256
+
+
+__device__ __forceinline__ float block_reduce_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < SAMP_THREADS / 64; ++i) t += red[i];
+    return t;
+}
+__device__ __forceinline__ float block_reduce_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int i = 1; i < SAMP_THREADS / 64; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+// Philox4x32-10 -> one uniform in (0,1]
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint32_t subseq) {
+    uint32_t c[4] = {(uint32_t)offset, (uint32_t)(offset >> 32), subseq, 0u};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+        c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+        k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+    }
+    return ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+// descending bitonic sort of (key,val) pairs in LDS; n2 = power of two
+__device__ void bitonic_desc(float* key, int* val, int n2) {
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < n2; i += SAMP_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool desc = (i & k) == 0;
+                    const float a = key[i], b = key[ixj];
+                    // order: larger first; NaN never produced here; ties keep lower index first
+                    const bool swap = desc ? (a < b || (a == b && val[i] > val[ixj])) : (a > b || (a == b && val[i] < val[ixj]));
+                    if (swap) {
+                        key[i] = b; key[ixj] = a;
+                        const int t = val[i]; val[i] = val[ixj]; val[ixj] = t;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
+    __shared__ float vals[SAMP_MAXV];
+    __shared__ float skey[SAMP_MAXV];
+    __shared__ int sidx[SAMP_MAXV];
+    __shared__ float red[SAMP_THREADS / 64];
+    __shared__ int s_flag;
+    __shared__ float s_f;
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int V = a.vocab;
+    const int item = a.row_item ? a.row_item[row] : row;
+    const float* lg = a.logits + (size_t)row * a.ld;
+    for (int v = tid; v < V; v += SAMP_THREADS) vals[v] = lg[v];
+    __syncthreads();
+
+    // previous tokens of this row's utterance
+    const int32_t* prev = nullptr;
+    int n_prev = 0;
+    if (a.prev_is_seq) {
+        n_prev = a.seq_len[item];
+        prev = a.seq + (size_t)item * a.seq_cap;
+    } else if (a.prev != nullptr) {
+        n_prev = a.prev_len[item];
+        prev = a.prev + a.prev_off[item];
+    }
+
+    // ---- repetition penalty (samplers.py:16-50)
+    if (a.p.repetition_penalty != 1.0f && prev != nullptr && n_prev > 0) {
+        int limit;
+        if (a.nar_mode) limit = a.row_in_item ? a.row_in_item[row] : 0;  // only tokens before this row
+        else limit = (n_prev == 1) ? 0 : n_prev;                           // 1 row & 1 prev => "NAR": start=1 empties the slice
+        if (limit > n_prev) limit = n_prev;
+        const double factor = (double)a.p.repetition_penalty, decay = (double)a.p.repetition_penalty_decay;
+        for (int pass = 0; pass < a.p.rep_pen_passes; ++pass) {
+            for (int v = tid; v < V; v += SAMP_THREADS) {
+                float x = vals[v];
+                for (int i = 0; i < limit; ++i) {
+                    if (prev[i] == v) {
+                        const double dist = (double)(n_prev - i);
+                        const float div = (float)(decay == 0.0 ? factor : factor * pow(dist, decay));
+                        x = x / div;
+                    }
+                }
+                vals[v] = x;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- length penalty, AR rows only (samplers.py:56-61; length = len(prev) + 1, base.py:1377)
+    if (!a.nar_mode && a.p.length_penalty != 0.0f && (prev != nullptr || a.prev_is_seq) && a.p.stop_token < V) {
+        if (tid == 0) {
+            const float div = (float)pow((double)(n_prev + 1), (double)a.p.length_penalty);
+            vals[a.p.stop_token] = vals[a.p.stop_token] / div;
+        }
+        __syncthreads();
+    }
+
+    const bool need_sort = a.p.top_k > 0 || a.p.top_p < 1.0f || a.p.min_p > 0.0f;
+    int n2 = 1;
+    while (n2 < V) n2 <<= 1;
+    auto sort_current = [&]() {
+        for (int i = tid; i < n2; i += SAMP_THREADS) {
+            skey[i] = i < V ? vals[i] : -INFINITY;
+            sidx[i] = i < V ? i : (1 << 30);
+        }
+        bitonic_desc(skey, sidx, n2);
+    };
+    // ---- min-p (samplers.py:74-90): drop p < min_p * p_max, but never the 32 largest
+    if (a.p.min_p > 0.0f) {
+        sort_current();
+        const float mx = skey[0];
+        float se = 0.f;
+        for (int v = tid; v < V; v += SAMP_THREADS) se += expf(vals[v] - mx);
+        se = block_reduce_sum(se, red);
+        const float thr = a.p.min_p * (1.0f / se);  // p_max = exp(0)/se
+        __syncthreads();
+        for (int j = tid; j < V; j += SAMP_THREADS) {
+            if (j >= 32) {
+                const int v = sidx[j];
+                if (expf(skey[j] - mx) / se < thr) vals[v] = -INFINITY;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- top-k (samplers.py:102-106): keep logits >= the k-th largest
+    if (a.p.top_k > 0) {
+        sort_current();
+        int k = a.p.top_k < 1 ? 1 : a.p.top_k;
+        if (k > V) k = V;
+        const float kth = skey[k - 1];
+        __syncthreads();
+        for (int v = tid; v < V; v += SAMP_THREADS) if (vals[v] < kth) vals[v] = -INFINITY;
+        __syncthreads();
+    }
+    // ---- top-p (samplers.py:108-123)
+    if (a.p.top_p < 1.0f) {
+        sort_current();
+        const float mx = skey[0];
+        // softmax of the sorted logits, inclusive cumsum (Hillis-Steele over n2 in LDS, reusing vals? no: use skey)
+        float se = 0.f;
+        for (int j = tid; j < V; j += SAMP_THREADS) se += expf(skey[j] - mx);
+        se = block_reduce_sum(se, red);
+        __syncthreads();
+        for (int j = tid; j < n2; j += SAMP_THREADS) skey[j] = j < V ? expf(skey[j] - mx) / se : 0.f;
+        __syncthreads();
+        // serial-chunk scan: each thread owns a contiguous chunk
+        const int chunk = n2 / SAMP_THREADS > 0 ? n2 / SAMP_THREADS : 1;
+        const int b0 = tid * chunk;
+        float run = 0.f;
+        if (b0 < n2) for (int j = b0; j < b0 + chunk; ++j) { run += skey[j]; skey[j] = run; }
+        __shared__ float chunk_tot[SAMP_THREADS];
+        chunk_tot[tid] = (b0 < n2) ? run : 0.f;
+        __syncthreads();
+        if (tid == 0) {
+            float acc = 0.f;
+            for (int t = 0; t < SAMP_THREADS; ++t) { const float c = chunk_tot[t]; chunk_tot[t] = acc; acc += c; }
+        }
+        __syncthreads();
+        if (b0 < n2) for (int j = b0; j < b0 + chunk; ++j) skey[j] += chunk_tot[tid];
+        __syncthreads();
+        // remove sorted position j >= 1 when cum[j-1] > top_p
+        for (int j = tid + 1; j < V; j += SAMP_THREADS)
+            if (skey[j - 1] > a.p.top_p) vals[sidx[j]] = -INFINITY;
+        __syncthreads();
+    }
+    (void)need_sort;
+    // ---- temperature
+    if (a.p.temperature > 0.0f) {
+        for (int v = tid; v < V; v += SAMP_THREADS) vals[v] = vals[v] / a.p.temperature;
+        __syncthreads();
+    }
+    // ---- top-n-sigma, n = 1 whenever top_no > 0 (base.py:1395-1396 passes no n; samplers.py:164-172)
+    if (a.p.top_no > 0.0f) {
+        float s = 0.f, mx = -INFINITY;
+        int bad = 0;
+        for (int v = tid; v < V; v += SAMP_THREADS) {
+            const float x = vals[v];
+            if (!(fabsf(x) <= 3.0e38f)) bad = 1;  // -inf / nan present: torch.std gives nan -> everything is masked
+            s += x; mx = fmaxf(mx, x);
+        }
+        if (tid == 0) s_flag = 0;
+        __syncthreads();
+        if (bad) s_flag = 1;
+        s = block_reduce_sum(s, red);
+        mx = block_reduce_max(mx, red);
+        const int any_bad = s_flag;
+        const float mean = s / (float)V;
+        float ss = 0.f;
+        for (int v = tid; v < V; v += SAMP_THREADS) { const float dlt = vals[v] - mean; ss += dlt * dlt; }
+        ss = block_reduce_sum(ss, red);
+        const float sd = sqrtf(ss / (float)(V - 1));
+        const float thr = mx - sd;
+        __syncthreads();
+        for (int v = tid; v < V; v += SAMP_THREADS) {
+            if (any_bad || !(vals[v] >= thr)) vals[v] = -INFINITY;
+        }
+        __syncthreads();
+    }
+    // ---- pick: argmax (lowest index on ties) or categorical
+    float mx = -INFINITY;
+    for (int v = tid; v < V; v += SAMP_THREADS) mx = fmaxf(mx, vals[v]);
+    mx = block_reduce_max(mx, red);
+    float se = 0.f;
+    for (int v = tid; v < V; v += SAMP_THREADS) se += expf(vals[v] - mx);
+    se = block_reduce_sum(se, red);   // all -inf: exp(nan) -> nan, like the reference's softmax
+    int tok;
+    if (a.p.temperature <= 0.0f) {
+        int best = 1 << 30;
+        for (int v = tid; v < V; v += SAMP_THREADS) if (vals[v] == mx && v < best) best = v;
+        if (tid == 0) s_flag = 1 << 30;
+        __syncthreads();
+        atomicMin(&s_flag, best);
+        __syncthreads();
+        tok = s_flag;
+        if (tok >= V) tok = 0;          // all -inf / nan row: torch.argmax returns 0
+    } else {
+        // inverse-CDF draw over the index order
+        if (tid == 0) {
+            const float u = philox_uniform(a.p.seed, a.p.offset + a.step, (uint32_t)row) * se;
+            float acc = 0.f;
+            int pick = -1, last_valid = 0;
+            for (int v = 0; v < V; ++v) {
+                const float e = expf(vals[v] - mx);
+                if (e > 0.f) last_valid = v;
+                acc += e;
+                if (pick < 0 && acc >= u) pick = v;
+            }
+            s_flag = pick < 0 ? last_valid : pick;
+        }
+        __syncthreads();
+        tok = s_flag;
+    }
+    if (tid == 0) {
+        a.ids[row] = tok;
+        const float sc = expf(vals[tok] - mx) / se;
+        if (a.scores) a.scores[row] = sc;
+        if (a.seq != nullptr) {  // fused AR append (models/ar_nar.py:837-842)
+            const int n = a.seq_len[item];
+            if (n < a.seq_cap) a.seq[(size_t)item * a.seq_cap + n] = tok;
+            a.seq_len[item] = n + 1;
+            a.ctx_len[item] = a.ctx_len[item] + 1;
+            if (tok == a.p.stop_token) a.stopped[item] = 1;
+        }
+    }
+    (void)s_f;
+}
+
+int valle_sample_launch(const SampleArgs& a, int rows, hipStream_t s) {
+    sample_kernel<<<rows, SAMP_THREADS, 0, s>>>(a);
+    VALLE_LAUNCH_CHECK();
+    return VALLE_OK;
+}
+
+extern "C" int valle_sample(const float* logits, int ld, int vocab, int rows, const int32_t* row_item,
+                            const int32_t* row_in_item, const int32_t* prev, const int32_t* prev_off,
+                            const int32_t* prev_len, int nar_mode, const valle_sample_params* params,
+                            int32_t* ids, float* scores, void* stream) {
+    VALLE_REQUIRE(logits && params && ids, VALLE_E_ARG, "valle_sample: null pointer");
+    VALLE_REQUIRE(vocab > 1 && vocab <= SAMP_MAXV && ld >= vocab, VALLE_E_ARG, "valle_sample: vocab %d (max %d), ld %d", vocab, SAMP_MAXV, ld);
+    VALLE_REQUIRE(prev == nullptr || (prev_off && prev_len), VALLE_E_ARG, "valle_sample: prev needs prev_off/prev_len");
+    VALLE_REQUIRE(params->rep_pen_passes >= 1 && params->rep_pen_passes <= 2, VALLE_E_ARG, "valle_sample: rep_pen_passes must be 1 or 2");
+    if (rows == 0) return VALLE_OK;
+    SampleArgs a{};
+    a.logits = logits; a.ld = ld; a.vocab = vocab; a.row_item = row_item; a.row_in_item = row_in_item;
+    a.prev = prev; a.prev_off = prev_off; a.prev_len = prev_len; a.nar_mode = nar_mode; a.p = *params;
+    a.ids = ids; a.scores = scores;
+    return valle_sample_launch(a, rows, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------- cfg_combine
+__global__ __launch_bounds__(1024) void cfg_combine_kernel(float* __restrict__ pos, const float* __restrict__ neg, int ld,
+                                                           int vocab, const int32_t* __restrict__ row_off,
+                                                           float strength, float rescale) {
+    const int i = blockIdx.x;
+    const int r0 = row_off[i], r1 = row_off[i + 1];
+    const long n = (long)(r1 - r0) * vocab;
+    if (n <= 0) return;
+    __shared__ double red[2][16];
+    __shared__ double stat[4];
+    auto block_sum2 = [&](double a, double b, double& oa, double& ob) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+        __syncthreads();
+        oa = 0; ob = 0;
+        for (int w = 0; w < 16; ++w) { oa += red[0][w]; ob += red[1][w]; }
+    };
+    float factor = 1.0f;
+    if (rescale > 0.f) {
+        double sp = 0, sm = 0;
+        for (long e = threadIdx.x; e < n; e += 1024) {
+            const size_t o = (size_t)(r0 + e / vocab) * ld + e % vocab;
+            const float p = pos[o], q = neg[o];
+            sp += p; sm += q + (p - q) * strength;
+        }
+        double tp, tm;
+        block_sum2(sp, sm, tp, tm);
+        const double mp = tp / n, mm = tm / n;
+        double vp = 0, vm = 0;
+        for (long e = threadIdx.x; e < n; e += 1024) {
+            const size_t o = (size_t)(r0 + e / vocab) * ld + e % vocab;
+            const float p = pos[o], q = neg[o];
+            const double dp = p - mp, dm = (double)(q + (p - q) * strength) - mm;
+            vp += dp * dp; vm += dm * dm;
+        }
+        double tvp, tvm;
+        block_sum2(vp, vm, tvp, tvm);
+        const float sdp = (float)sqrt(tvp / (n - 1)), sdm = (float)sqrt(tvm / (n - 1));
+        factor = rescale * (sdp / sdm) + (1.0f - rescale);
+    }
+    __syncthreads();
+    for (long e = threadIdx.x; e < n; e += 1024) {
+        const size_t o = (size_t)(r0 + e / vocab) * ld + e % vocab;
+        const float p = pos[o], q = neg[o];
+        float s = q + (p - q) * strength;
+        if (rescale > 0.f) s = s * factor;
+        pos[o] = s;
+    }
+    (void)stat;
+}
+
+extern "C" int valle_cfg_combine(float* pos, const float* neg, int ld, int vocab, const int32_t* row_off, int B,
+                                 float strength, float rescale, void* stream) {
+    VALLE_REQUIRE(pos && neg && row_off, VALLE_E_ARG, "valle_cfg_combine: null pointer");
+    VALLE_REQUIRE(vocab > 0 && ld >= vocab, VALLE_E_ARG, "valle_cfg_combine: bad vocab/ld");
+    if (B == 0) return VALLE_OK;
+    cfg_combine_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(pos, neg, ld, vocab, row_off, strength, rescale);
+    VALLE_LAUNCH_CHECK();
+    return VALLE_OK;
+}
+
+// ---------------------------------------------------------------------- mask_lowest
+#define MASK_MAXN 8192
+__global__ __launch_bounds__(256) void mask_lowest_kernel(const float* __restrict__ scores, int32_t* __restrict__ codes,
+                                                          uint8_t* __restrict__ is_masked, const int32_t* __restrict__ off,
+                                                          const int32_t* __restrict__ kk, int mask_token) {
+    __shared__ float s[MASK_MAXN];
+    const int i = blockIdx.x;
+    const int o = off[i], n = off[i + 1] - o;
+    const int k = kk[i];
+    for (int j = threadIdx.x; j < n; j += 256) s[j] = scores[o + j];
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const float x = s[j];
+        int rank = 0;
+        for (int t = 0; t < n; ++t) {
+            const float y = s[t];
+            rank += (y < x) || (y == x && t < j);
+        }
+        int c = codes[o + j];
+        if (rank < k) c = mask_token;
+        codes[o + j] = c;
+        is_masked[o + j] = (c == mask_token);
+    }
+}
+
+extern "C" int valle_mask_lowest(const float* scores, int32_t* codes, uint8_t* is_masked, const int32_t* off,
+                                 const int32_t* k, int B, int max_len, int mask_token, void* stream) {
+    VALLE_REQUIRE(scores && codes && is_masked && off && k, VALLE_E_ARG, "valle_mask_lowest: null pointer");
+    VALLE_REQUIRE(max_len >= 0 && max_len <= MASK_MAXN, VALLE_E_UNSUPPORTED, "valle_mask_lowest: %d positions per utterance (max %d)", max_len, MASK_MAXN);
+    if (B == 0) return VALLE_OK;
+    mask_lowest_kernel<<<B, 256, 0, (hipStream_t)stream>>>(scores, codes, is_masked, off, k, mask_token);
+    VALLE_LAUNCH_CHECK();
+    return VALLE_OK;
+}

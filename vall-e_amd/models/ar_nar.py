@@ -1,0 +1,319 @@
+"""AR_NAR: the reference's inference entry points on the HIP path.
+
+Same call surface as ``vall_e.models.ar_nar.AR_NAR`` (reference models/ar_nar.py:34-983):
+``model(task_list=, phns_list=, proms_list=, resps_list=, lang_list=, len_list=, **sampling_kwargs)``
+dispatches to ``forward_ar`` / ``forward_nar`` / ``forward_nar_masked`` exactly as
+ar_nar.py:892-983 does.  The AR loop keeps a KV cache on the device (the reference recomputes
+the whole sequence every step, base.py:521) and runs steps in chunks with no host sync inside.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from .base import Base, Logits, _np, _round_up
+
+
+def convert_kwargs(kwargs, prefix):
+    """utils/utils.py:46-56."""
+    for key in list(kwargs):
+        if key.startswith(prefix):
+            kwargs[key[len(prefix):]] = kwargs.pop(key)
+    return kwargs
+
+
+def clamp(n, lo, hi):
+    return max(lo, min(n, hi))
+
+
+class AR_NAR(Base):
+    # ---------------------------------------------------------------- lower-level surface
+    def forward_super(self, inputs, quant_levels=None, state=None, output_attentions=False, output_hidden_states=False):
+        """Base.forward on an explicit batch description: ``inputs`` is a dict with the keyword
+        lists of ``plan`` (phns_list, lang_list, proms_list, resps_list) -- all rows' logits."""
+        if output_attentions or output_hidden_states or state is not None:
+            raise NotImplementedError("attentions / hidden states / external state are not exposed")
+        q = 0 if quant_levels is None else int(quant_levels[0])
+        if quant_levels is not None and any(int(x) != q for x in quant_levels):
+            raise NotImplementedError("one quant level per batch")
+        plan = self.plan(inputs.get("phns_list"), inputs.get("lang_list"), inputs.get("proms_list"),
+                         inputs["resps_list"], q, timestep=inputs.get("timestep", False))
+        rows, off = self.tail_rows(plan, plan.lens)
+        lg = self.forward_dense(plan, rows)
+        V = self.cls_tokens[plan.head]
+        return Logits([lg[off[i]:off[i + 1], :V] for i in range(plan.B)], None, inputs, None, None, None)
+
+    # ------------------------------------------------------------------------------ dispatch
+    def forward(self, task_list=None, phns_list=None, proms_list=None, resps_list=None, lang_list=None, tone_list=None,
+                len_list=None, text_list=None, training=None, disable_tqdm=False, use_lora=None, **sampling_kwargs):
+        if text_list is not None or tone_list is not None:
+            raise NotImplementedError("raw-text / tone inputs are outside the built path")
+        if task_list is not None and any(t != "tts" for t in task_list):
+            raise NotImplementedError(f"tasks {sorted(set(task_list))}: only 'tts' (AR, NAR, NAR-len) is built")
+        if training:
+            raise NotImplementedError("training is out of scope")
+        if training is None and phns_list is not None and resps_list is not None:
+            levels = {(_np(r).shape[-1] if _np(r).ndim > 1 else 1) for r in resps_list}
+            if next(iter(levels)) == self.n_resp_levels:                    # ar_nar.py:927-931
+                raise NotImplementedError("resps with all levels means training in the reference; out of scope")
+        if (len_list is not None or resps_list is not None) and phns_list is not None:
+            return self.forward_nar(task_list=task_list, phns_list=phns_list, proms_list=proms_list, resps_list=resps_list,
+                                    lang_list=lang_list, len_list=len_list, **sampling_kwargs)
+        return self.forward_ar(task_list=task_list, phns_list=phns_list, proms_list=proms_list, resps_list=resps_list,
+                               lang_list=lang_list, **sampling_kwargs)
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------------------------ AR
+    def forward_ar(self, task_list=None, phns_list=None, proms_list=None, resps_list=None, lang_list=None,
+                   disable_tqdm=False, use_lora=None, **sampling_kwargs):
+        """Level-0 autoregressive loop, ar_nar.py:588-890 (tts task)."""
+        self._prepare()
+        lib = L.load()
+        kw = convert_kwargs(dict(sampling_kwargs), "ar_")
+        cfg_strength = kw.get("cfg_strength", 0.0)
+        cfg_rescale = kw.pop("cfg_rescale", 0.7)
+        max_duration = kw.get("max_duration", 500)
+        step_chunk = int(kw.pop("step_chunk", 32))
+        return_logits = kw.pop("return_logits", False)
+        prefix_context = kw.get("prefix_context", None)
+        sp = self.sample_params(**kw)
+        B = len(phns_list)
+        dev = self.device
+        n_steps = max_duration // max(1, self.causal_size)
+
+        prefix = [np.zeros(0, np.int64) for _ in range(B)]
+        prefix_lens = [0] * B
+        if prefix_context is not None:                                        # ar_nar.py:736-742
+            prefix_text, prefix_resps, prefix_lens = prefix_context
+            phns_list = [torch.cat([torch.as_tensor(p)[:-1], torch.as_tensor(t)[1:]]) for p, t in zip(prefix_text, phns_list)]
+            prefix = [(_np(r) if _np(r).ndim == 1 else _np(r)[:, 0]) for r in prefix_resps]
+
+        passes = [(phns_list, proms_list)]
+        if cfg_strength > 0:                                                  # null text / no prompt (ar_nar.py:744-745)
+            passes.append(([torch.tensor([1, 2]) for _ in range(B)], None))
+
+        V = self.cls_tokens[0]
+        ld = _round_up(V, 8)
+        H, Dh, Lyr = self.n_heads, self.d_model // self.n_heads, self.n_layers
+        cap = max(len(p) for p in prefix) + n_steps + 1
+        seq = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+        for i, p in enumerate(prefix):
+            if len(p):
+                seq[i, : len(p)] = torch.from_numpy(p.astype(np.int32)).to(dev)
+        seq_len = self._i32([len(p) for p in prefix])
+        stopped = torch.zeros(B, dtype=torch.int32, device=dev)
+        scores = torch.zeros(B, dtype=torch.float32, device=dev)
+        resp_pos0 = torch.zeros(B, dtype=torch.int32, device=dev)
+        slot = torch.arange(B, dtype=torch.int32, device=dev)
+
+        states, first_logits = [], []
+        for phns, proms in passes:
+            plan = self.plan(phns, lang_list, proms, [torch.from_numpy(p) for p in prefix], 0)
+            cache_T = _round_up(plan.max_T + n_steps + 1, 8)
+            stride = B * H * cache_T * Dh
+            kc = torch.empty((Lyr, B, H, cache_T, Dh), dtype=self.dtype, device=dev)
+            vc = torch.empty_like(kc)
+            rows, off = self.tail_rows(plan, [1] * B)
+            pos0 = torch.zeros(B, dtype=torch.int32, device=dev)
+            lg = self.forward_dense(plan, rows, cache=(kc, vc, cache_T, stride, slot, pos0))
+            ctx_len = self._i32(plan.lens)
+            st = L.ARState(B, cap, seq.data_ptr(), seq_len.data_ptr(), ctx_len.data_ptr(), resp_pos0.data_ptr(),
+                           slot.data_ptr(), stopped.data_ptr(), scores.data_ptr(), kc.data_ptr(), vc.data_ptr(),
+                           cache_T, stride, self._off["resp0"], 0, V)
+            states.append((st, (kc, vc, ctx_len)))
+            first_logits.append(lg)
+        ws_bytes = lib.valle_decode_workspace_bytes(self._handle, B)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        stream = L.stream_ptr(dev)
+        all_logits = []
+
+        if cfg_strength <= 0:
+            # step 0: sample from the prefill's last row, then chunks of cached steps
+            st = states[0][0]
+            if return_logits:
+                all_logits.append(first_logits[0][:, :V].clone())
+            self._ar_sample_append(first_logits[0], V, seq, seq_len, [states[0][1][2]], stopped, scores, sp, cap, step=0)
+            done = 1
+            while done < n_steps:
+                if bool(stopped.all().item()):                                # ar_nar.py:846 (checked once per chunk)
+                    break
+                n = min(step_chunk, n_steps - done)
+                lg_out = torch.empty((n, B, ld), dtype=torch.float32, device=dev) if return_logits else None
+                sp.offset = done
+                L.check(lib.valle_ar_decode(self._handle, C.byref(st), C.byref(sp), n, L.ptr(lg_out), ld,
+                                            L.ptr(ws), ws.numel(), stream))
+                if return_logits:
+                    all_logits.extend(lg_out[j, :, :V] for j in range(n))
+                done += n
+        else:
+            # classifier-free guidance: positive and null caches advance together; the combine
+            # needs every response row's logits (std over rows x vocab, samplers.py:187-188), which
+            # under causality are the last-row logits of the earlier steps -> keep a history
+            hist = [torch.empty((B, n_steps + 1, ld), dtype=torch.float32, device=dev) for _ in range(2)]
+            n_prefix = [len(p) for p in prefix]
+            if any(n_prefix):
+                raise NotImplementedError("prefix_context together with AR classifier-free guidance")
+            for step in range(n_steps):
+                for k in range(2):
+                    if step == 0:
+                        hist[k][:, 0] = first_logits[k]
+                    else:
+                        lg = torch.empty((B, ld), dtype=torch.float32, device=dev)
+                        L.check(lib.valle_ar_decode(self._handle, C.byref(states[k][0]), None, 1, L.ptr(lg), ld,
+                                                    L.ptr(ws), ws.numel(), stream))
+                        hist[k][:, step] = lg
+                n_rows = step + 1
+                posl = hist[0][:, :n_rows].reshape(B * n_rows, ld).contiguous()
+                negl = hist[1][:, :n_rows].reshape(B * n_rows, ld).contiguous()
+                self.cfg_combine(posl, negl, V, np.arange(B + 1, dtype=np.int32) * n_rows, cfg_strength, cfg_rescale)
+                last = posl.view(B, n_rows, ld)[:, -1].contiguous()
+                if return_logits:
+                    all_logits.append(last[:, :V].clone())
+                self._ar_sample_append(last, V, seq, seq_len, [states[0][1][2], states[1][1][2]], stopped, scores, sp, cap,
+                                       step=step, bump_ctx=step > 0)
+                if bool(stopped.all().item()):
+                    break
+        torch.cuda.synchronize(dev)
+        seq_h, len_h = seq.cpu().numpy(), seq_len.cpu().numpy()
+        out = []
+        for i in range(B):
+            r = seq_h[i, : len_h[i]].astype(np.int64)
+            hit = np.nonzero(r == self.stop_token)[0]                         # _prune, base.py:290-299
+            if len(hit):
+                r = r[: hit.min()]
+            r = r[prefix_lens[i] if prefix_context is not None else 0:]       # ar_nar.py:886-888
+            out.append(torch.from_numpy(r).to(dev))
+        if return_logits:
+            return out, all_logits
+        return out
+
+    def _ar_sample_append(self, logits, V, seq, seq_len, ctx_lens, stopped, scores, sp, cap, step, bump_ctx=False):
+        """Sampling of one AR row per utterance from explicit logits + token append (host-driven
+        steps: the prefill row and the CFG path).  prev = the sequence so far (ar_nar.py:804-808)."""
+        lib = L.load()
+        B = seq.shape[0]
+        prev_off = torch.arange(B, dtype=torch.int32, device=self.device) * cap
+        ids = torch.empty(B, dtype=torch.int32, device=self.device)
+        sp.offset = step
+        L.check(lib.valle_sample(L.ptr(logits), logits.shape[1], V, B, None, None, L.ptr(seq), L.ptr(prev_off),
+                                 L.ptr(seq_len), 0, C.byref(sp), L.ptr(ids), L.ptr(scores), L.stream_ptr(self.device)))
+        seq.scatter_(1, seq_len.long()[:, None].clamp_(max=cap - 1), ids[:, None])
+        seq_len += 1
+        stopped |= (ids == self.stop_token).int()
+        if bump_ctx:                      # cached positions grow when a token was run through the stack
+            for c in ctx_lens:
+                c += 1
+
+    # ----------------------------------------------------------------------------------- NAR
+    def forward_nar(self, task_list=None, phns_list=None, proms_list=None, resps_list=None, lang_list=None,
+                    len_list=None, disable_tqdm=False, use_lora=None, **sampling_kwargs):
+        """Levels 1..max_levels, one dense pass per level (ar_nar.py:466-586)."""
+        if len_list is not None:                                              # ar_nar.py:485-496
+            resps_list = self.forward_nar_masked(task_list=task_list, phns_list=phns_list, proms_list=proms_list,
+                                                 resps_list=resps_list, lang_list=lang_list, len_list=len_list,
+                                                 **sampling_kwargs)
+        kw = convert_kwargs(dict(sampling_kwargs), "nar_")
+        max_levels = kw.get("max_levels", 0)
+        cfg_strength = kw.get("cfg_strength", 0.0)
+        cfg_rescale = kw.pop("cfg_rescale", 0.7)
+        if max_levels == 0:
+            max_levels = self.n_max_levels - 1
+        B = len(resps_list)
+        # the reference mutates the caller's list in place (ar_nar.py:523-525); keep that
+        for i, r in enumerate(resps_list):
+            if r.dim() == 1:
+                resps_list[i] = r.unsqueeze(-1)
+        prev = [r.to(self.device).long() for r in resps_list]
+        sp = self.sample_params(**kw)
+        null_text = [torch.tensor([1, 2]) for _ in range(B)]
+        for n in range(max_levels):
+            level = prev[0].shape[-1]
+            if level >= max_levels + 1:
+                break
+            R = [p.shape[0] for p in prev]
+            plan = self.plan(phns_list, lang_list, proms_list, prev, level)
+            rows, off = self.tail_rows(plan, R)
+            logits = self.forward_dense(plan, rows)
+            V = self.cls_tokens[plan.head]
+            if cfg_strength > 0:
+                nplan = self.plan(null_text, lang_list, None, prev, level)
+                nrows, _ = self.tail_rows(nplan, R)
+                null = self.forward_dense(nplan, nrows)
+                self.cfg_combine(logits, null, V, off, cfg_strength, cfg_rescale)
+            sp.offset = 1000 + n
+            ids, _ = self.sample_rows(logits, V, off, prev, nar_mode=1, params=sp)
+            ids = ids.long()
+            prev = [torch.cat([p, ids[off[i]:off[i + 1], None]], dim=-1) for i, p in enumerate(prev)]
+        return prev
+
+    # ------------------------------------------------------------------------------- NAR-len
+    def forward_nar_masked(self, task_list=None, phns_list=None, proms_list=None, resps_list=None, lang_list=None,
+                           len_list=None, quant_levels=None, disable_tqdm=False, use_lora=None, **sampling_kwargs):
+        """Level-0 iterative demasking (ar_nar.py:233-464)."""
+        self._prepare()
+        lib = L.load()
+        kw = convert_kwargs(dict(sampling_kwargs), "ar_")                     # (sic) ar_nar.py:282
+        min_length = kw.pop("min_duration", 1)
+        max_length = kw.pop("max_duration", 500)
+        max_steps = kw.get("max_steps", 25)
+        annealed = kw.get("annealed_sampling", True)
+        temperature = kw.pop("temperature", 0.0)
+        min_cfg = kw.get("minimum_cfg_strength", 2.5)
+        cfg_strength = max(kw.get("cfg_strength", min_cfg), min_cfg)           # ar_nar.py:293-295, :319
+        cfg_rescale = kw.pop("cfg_rescale", 0.75)
+        start_noise, end_noise = kw.get("denoise_start", 0.0), kw.get("denoise_end", 1.0)
+        max_steps = math.floor(max_steps * (end_noise - start_noise))
+        remasking = kw.get("sampling_scores_remask", False)
+        for k in ("sampling_scores_masked_only", "vc_list", "prefix_context"):
+            if kw.get(k):
+                raise NotImplementedError(f"{k} is not built on the HIP path")
+        if start_noise > 0.0:
+            raise NotImplementedError("denoising from an existing sequence (denoise_start > 0)")
+        if quant_levels is not None and any(q != 0 for q in quant_levels):
+            raise NotImplementedError("demasking levels other than 0")
+        lens = [clamp(int(l), min_length, max_length) for l in len_list]
+        B, dev = len(lens), self.device
+        off = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+        off_d = self._i32(off)
+        total = int(off[-1])
+        codes = torch.full((total,), self.mask_token, dtype=torch.int32, device=dev)
+        scores = torch.ones(total, dtype=torch.float32, device=dev)
+        is_masked = torch.empty(total, dtype=torch.uint8, device=dev)
+        null_text = [torch.tensor([1, 2]) for _ in range(B)]
+        V = self.cls_tokens[self.cls_names.index("NAR:0:0")]
+        stream = L.stream_ptr(dev)
+        for step, t in enumerate(torch.linspace(start_noise, end_noise, max_steps)):
+            noise_p = math.cos(t * math.pi * 0.5)                               # float32 timestep, as the reference
+            mask_p = noise_p + (1.0 / (max_steps * 2) if remasking else 0)
+            ks = self._i32([clamp(int(mask_p * n), 1, n - step) for n in lens])  # ar_nar.py:358
+            prev_codes = codes.clone()
+            L.check(lib.valle_mask_lowest(L.ptr(scores), L.ptr(codes), L.ptr(is_masked), L.ptr(off_d), L.ptr(ks), B,
+                                          max(lens), self.mask_token, stream))
+            temp = temperature * (1.0 - float(t)) if annealed else temperature
+            codes_h = codes.cpu().numpy()
+            resps = [codes_h[off[i]:off[i + 1]] for i in range(B)]
+            plan = self.plan(phns_list, lang_list, proms_list, resps, 0, timestep=True)
+            rows, roff = self.tail_rows(plan, lens)
+            logits = self.forward_dense(plan, rows)
+            if cfg_strength > 0:
+                nplan = self.plan(null_text, lang_list, None, resps, 0, timestep=True)
+                nrows, _ = self.tail_rows(nplan, lens)
+                null = self.forward_dense(nplan, nrows)
+                self.cfg_combine(logits, null, V, roff, cfg_strength, cfg_rescale)
+            prev = [prev_codes[off[i]:off[i + 1]] for i in range(B)]
+            sp1 = self.sample_params(temperature=temp, **kw)
+            sp1.offset = 2000 + step
+            ids, _ = self.sample_rows(logits, V, roff, prev, nar_mode=1, params=sp1)
+            # the reference's second ("unfiltered") sample runs on tensors its in-place processors
+            # have already touched: the repetition penalty is applied a second time
+            sp2 = self.sample_params(temperature=0.0, rep_pen_passes=2 if kw.get("repetition_penalty", 1.0) != 1.0 else 1, **kw)
+            _, sc = self.sample_rows(logits, V, roff, prev, nar_mode=1, params=sp2)
+            codes = torch.where(is_masked.bool(), ids, codes)                  # ar_nar.py:457
+            scores = sc                                                        # ar_nar.py:462
+        codes = codes.to(torch.int16)
+        return [codes[off[i]:off[i + 1]] for i in range(B)]

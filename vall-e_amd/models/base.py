@@ -1,0 +1,382 @@
+"""Host side of the HIP path: weight preparation, sequence planning, kernel-call wrappers.
+
+Mirrors ``vall_e.models.base.Base`` (reference models/base.py:284-1430) for the inference
+path: same constructor arguments, same state-dict names, same ``sample`` kwargs.  All
+arithmetic happens in libvalle_hip.so; torch is used to allocate device buffers and to move
+integer bookkeeping (ids, offsets) to the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from ..config import Model as ModelConfig, repo_default_model
+from ..weights import classifier_layout, state_dict_spec
+
+Logits = namedtuple("Logits", ["logits", "state", "inputs", "loss", "attentions", "hidden_states"])  # base.py:46
+Sampled = namedtuple("Sampled", ["ids", "logits", "scores", "entropy"])                             # base.py:47
+
+UNSUPPORTED_SAMPLERS = ("beam_width", "mirostat_tau", "mirostat_eta", "dry_multiplier", "entropix_sampling",
+                        "refine_on_stop", "input_prompt_prefix", "prefix_silence", "layer_skip")
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class Plan:
+    """Packed description of a batch of sequences (what Base.inputs + inputs_to_embeddings +
+    inputs_to_position_ids produce, base.py:560-735, :774-922, :949-996), as integer tables."""
+
+    __slots__ = ("idx", "pos", "cu", "lens", "out_len", "head", "B", "M", "max_T")
+
+    def __init__(self, idx, pos, lens, out_len, head):
+        self.idx, self.pos, self.lens, self.out_len, self.head = idx, pos, lens, out_len, head
+        self.B = len(lens)
+        self.cu = np.zeros(self.B + 1, dtype=np.int32)
+        np.cumsum(lens, out=self.cu[1:])
+        self.M = int(self.cu[-1])
+        self.max_T = int(max(lens))
+
+
+class Base:
+    def __init__(self, n_phn_tokens=256, n_audio_tokens=1024, n_text_tokens=8575, d_model=512, d_ffn=4, n_heads=8,
+                 n_layers=12, p_dropout=0.1, n_experts=1, l_padding=0, training=True, attention=None, config=None):
+        if config is None:
+            raise ValueError("config is required (the reference dereferences it too, models/base.py:340)")
+        if not isinstance(config, ModelConfig):
+            config = ModelConfig.from_dict({k: getattr(config, k) for k in
+                                            ("name", "version", "size", "tasks", "langs", "tones", "arch_type", "attention",
+                                             "dropout", "capabilities") if hasattr(config, k)} |
+                                           {"experimental": getattr(config, "experimental", None)})
+        exp = config.experimental
+        if config.arch_type != "llama":
+            raise NotImplementedError(f"arch_type {config.arch_type!r}: only the llama stack is built")
+        if config.version != 5 or not exp.split_classifiers or exp.audio_embedding_sums is not True:
+            raise NotImplementedError("built for the repo-default model family: version 5, split classifiers, summed audio embeddings")
+        if exp.causal_size != 1:
+            raise NotImplementedError("causal_size != 1")
+        if n_experts != 1:
+            raise NotImplementedError("MoE")
+        if d_model // n_heads != 64:
+            raise NotImplementedError("head_dim must be 64")
+        self.config = config
+        self.training = False
+        self.n_phn_tokens, self.n_audio_tokens, self.n_text_tokens = n_phn_tokens, n_audio_tokens, n_text_tokens
+        self.d_model, self.n_heads, self.n_layers, self.d_ffn = d_model, n_heads, n_layers, d_ffn
+        self.n_resp_levels = config.resp_levels
+        self.n_max_levels = config.max_levels
+        self.capabilities = list(config.capabilities) + ["lang"]          # base.py:444
+        self.stop_token = n_audio_tokens
+        self.mask_token = self.stop_token
+        self.causal = True
+        self.version = config.version
+        self.causal_size = exp.causal_size
+        self.unified_position_ids = exp.unified_position_ids
+        self.noncausal_masks = exp.noncausal_masks
+        self.masking_ratio = exp.masking_ratio
+        self.max_position_embeddings = exp.max_position_embeddings
+        self.emb_names, self.emb_tokens, self.cls_names, self.cls_tokens = classifier_layout(config)
+        self.device = torch.device("cpu")
+        self.dtype = torch.float32
+        self._off, self._table_order = self._table_offsets()
+        self._sd = None
+        self._handle = None
+        self._bufs = {}
+        self._ws = None
+        self._keep = []
+
+    # ------------------------------------------------------------- nn.Module-ish surface
+    def state_dict_spec(self):
+        return state_dict_spec(self.config)
+
+    def load_state_dict(self, sd, strict=True):
+        spec = self.state_dict_spec()
+        missing = [k for k in spec if k not in sd]
+        if strict and missing:
+            raise KeyError(f"missing keys: {missing[:5]}...")
+        for k, shape in spec.items():
+            if k in sd and tuple(sd[k].shape) != tuple(shape):
+                raise ValueError(f"{k}: shape {tuple(sd[k].shape)} != {shape}")
+        self._sd = {k: sd[k].detach().to("cpu", torch.float32) for k in spec if k in sd}
+        self._release()
+        return self
+
+    def eval(self):
+        return self
+
+    def float(self):
+        return self.to(dtype=torch.float32)
+
+    def bfloat16(self):
+        return self.to(dtype=torch.bfloat16)
+
+    def to(self, device=None, dtype=None):
+        if isinstance(device, torch.dtype):
+            device, dtype = None, device
+        if device is not None:
+            self.device = torch.device(device)
+        if dtype is not None:
+            L.dtype_code(dtype)
+            self.dtype = dtype
+        self._release()
+        return self
+
+    def _release(self):
+        if self._handle is not None:
+            L.load().valle_model_destroy(self._handle)
+        self._handle, self._bufs, self._ws, self._keep = None, {}, None, []
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weight preparation
+    def _table_offsets(self):
+        """Row offsets of every embedding table inside the one concatenated table."""
+        spec = self.state_dict_spec()
+        order = [("text", "text_emb.weight"), ("rvq", "rvq_l_emb.weight"), ("lang", "langs_emb.weight"),
+                 ("task", "tasks_emb.weight"), ("len", "len_emb.weight"), ("tone", "tones_emb.weight"), ("sep", "sep")]
+        order += [(f"prom{l}", f"proms_emb.embeddings.{l}.weight") for l in range(self.n_resp_levels)]
+        order += [(f"resp{l}", f"resps_emb.embeddings.{l}.weight") for l in range(len(self.emb_tokens))]
+        order = [(n, k) for n, k in order if k in spec]
+        off, row = {}, 0
+        for name, key in order:
+            off[name] = row
+            row += 1 if len(spec[key]) == 1 else spec[key][0]
+        return off, order
+
+    def _prepare(self):
+        if self._handle is not None:
+            return
+        if self._sd is None:
+            raise RuntimeError("load_state_dict first")
+        if self.device.type != "cuda":
+            raise L.ValleHipError("the HIP path needs a GPU device (model.to('cuda')); there is no CPU fallback")
+        lib = L.load()
+        sd, dev, dt = self._sd, self.device, self.dtype
+        d, H, ff = self.d_model, self.n_heads, self.d_model * self.d_ffn
+        off = self._off
+        # concatenated embedding table (row offsets: _table_offsets)
+        tabs = [sd[key].reshape(-1, d) for _, key in self._table_order]
+        b = self._bufs
+        b["emb"] = torch.cat(tabs).to(dev, dt).contiguous()
+        # RoPE table, computed exactly as the reference does (arch/llama.py:118-127): fp32
+        # outer product of positions and inv_freq, then cos / sin
+        Dh = d // H
+        inv_freq = 1.0 / (10000.0 ** (torch.arange(0, Dh, 2, dtype=torch.int64).float() / Dh))
+        pos = torch.arange(self.max_position_embeddings, dtype=torch.float32)
+        freqs = (inv_freq[None, :, None] @ pos[None, None, :]).transpose(1, 2)[0]      # (P, Dh/2)
+        b["rope"] = torch.stack((freqs.cos(), freqs.sin()), dim=-1).to(dev).contiguous()  # (P, Dh/2, 2) fp32
+        # per-head row permutation that makes RoPE pairs adjacent: (0,32,1,33,...)
+        perm_head = torch.stack((torch.arange(Dh // 2), torch.arange(Dh // 2) + Dh // 2), dim=1).reshape(-1)
+        perm = (torch.arange(H)[:, None] * Dh + perm_head[None, :]).reshape(-1)
+        layers = (L.LayerWeights * self.n_layers)()
+        for l in range(self.n_layers):
+            p = f"model.layers.{l}."
+            wq, wk, wv = (sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv")
+            b[f"qkv{l}"] = torch.cat((wq[perm], wk[perm], wv)).to(dev, dt).contiguous()
+            b[f"o{l}"] = sd[p + "self_attn.o_proj.weight"].to(dev, dt).contiguous()
+            gu = torch.stack((sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]), dim=1).reshape(2 * ff, d)
+            b[f"gu{l}"] = gu.to(dev, dt).contiguous()
+            b[f"down{l}"] = sd[p + "mlp.down_proj.weight"].to(dev, dt).contiguous()
+            b[f"ln1_{l}"] = sd[p + "input_layernorm.weight"].to(dev, dt).contiguous()
+            b[f"ln2_{l}"] = sd[p + "post_attention_layernorm.weight"].to(dev, dt).contiguous()
+            layers[l] = L.LayerWeights(b[f"ln1_{l}"].data_ptr(), b[f"qkv{l}"].data_ptr(), b[f"o{l}"].data_ptr(),
+                                       b[f"ln2_{l}"].data_ptr(), b[f"gu{l}"].data_ptr(), b[f"down{l}"].data_ptr())
+        b["norm"] = sd["model.norm.weight"].to(dev, dt).contiguous()
+        n_cls = len(self.cls_tokens)
+        hw, hb, hn = (C.c_void_p * n_cls)(), (C.c_void_p * n_cls)(), (C.c_int32 * n_cls)()
+        for k in range(n_cls):
+            b[f"hw{k}"] = sd[f"classifiers.proj.{k}.weight"].to(dev, dt).contiguous()
+            hw[k] = b[f"hw{k}"].data_ptr()
+            bias = sd.get(f"classifiers.proj.{k}.bias")
+            if bias is not None:
+                b[f"hb{k}"] = bias.to(dev, torch.float32).contiguous() if dt == torch.float32 else bias.to(dt).to(dev, torch.float32).contiguous()
+                hb[k] = b[f"hb{k}"].data_ptr()
+            else:
+                hb[k] = None
+            hn[k] = self.cls_tokens[k]
+        cfg = L.Config(d, H, self.n_layers, ff, L.dtype_code(dt), 1e-6, self.max_position_embeddings)
+        handle = C.c_void_p()
+        L.check(lib.valle_model_create(C.byref(cfg), L.ptr(b["emb"]), L.ptr(b["rope"]), layers, L.ptr(b["norm"]), n_cls,
+                                       hw, hb, hn, C.byref(handle)))
+        self._handle = handle
+        self._keep = [layers, hw, hb, hn]
+
+    # -------------------------------------------------------------------- sequence planning
+    def plan(self, phns_list, lang_list, proms_list, resps_list, quant_level, *, timestep=False) -> Plan:
+        """TTS layout phn, lang, quant_level, prom, resp with a ``sep`` row between segments
+        (base.py:603-649, :101-110); classifier level per base.py:618/:628; position ids restart per
+        segment, non-output segments count their trailing sep (base.py:984)."""
+        off = self._off
+        B = len(resps_list)
+        q = quant_level
+        idx_all, pos_all, lens, out_len = [], [], [], []
+        sep_row = np.full((1, 8), -1, dtype=np.int32)
+        sep_row[0, 0] = off["sep"]
+
+        def rows1(base, ids):
+            r = np.full((len(ids), 8), -1, dtype=np.int32)
+            r[:, 0] = base + ids
+            return r
+
+        for i in range(B):
+            segs = []
+            if phns_list is not None and phns_list[i] is not None:
+                segs.append(("phn", rows1(off["text"], _np(phns_list[i]))))
+            if "lang" in self.capabilities and lang_list is not None and lang_list[i] is not None:
+                segs.append(("lang", rows1(off["lang"], _np(lang_list[i]))))
+            segs.append(("quant_level", rows1(off["rvq"], np.array([q]))))
+            if proms_list is not None and proms_list[i] is not None:
+                prom = proms_list[i]
+                if isinstance(prom, (list, tuple)):
+                    raise NotImplementedError("task tokens inside the prompt (tts-c/ns/sr) are outside this path")
+                prom = _np(prom)
+                if prom.ndim == 1:
+                    segs.append(("prom", rows1(off["prom0"], prom)))
+                else:
+                    n = 1 if q == 0 else q                                            # base.py:790-794
+                    r = np.full((prom.shape[0], 8), -1, dtype=np.int32)
+                    for l in range(n):
+                        r[:, l] = off[f"prom{l}"] + prom[:, l]
+                    segs.append(("prom", r))
+            resp = resps_list[i]
+            if resp is not None:
+                resp = _np(resp)
+                if timestep:                                                          # NAR-len: base.py:869-874
+                    col = resp if resp.ndim == 1 else resp[:, q]
+                    segs.append(("resp", rows1(off[f"resp{self.emb_names.index('NAR:0:0')}"], col)))
+                elif q == 0:                                                          # AR: base.py:893-899
+                    col = resp if resp.ndim == 1 else resp[:, 0]
+                    segs.append(("resp", rows1(off["resp0"], col)))
+                else:                                                                 # NAR q: sum of levels < q, tables 1..q
+                    if resp.ndim == 1:
+                        resp = resp[:, None]
+                    r = np.full((resp.shape[0], 8), -1, dtype=np.int32)
+                    for l in range(q):
+                        r[:, l] = off[f"resp{l + 1}"] + resp[:, l]
+                    segs.append(("resp", r))
+            parts, pos = [], []
+            for j, (kind, r) in enumerate(segs):
+                if j:
+                    parts.append(sep_row)
+                parts.append(r)
+                pos.append(np.arange(r.shape[0] + (0 if kind == "resp" else 1), dtype=np.int32))
+            idx = np.concatenate(parts)
+            pos = np.concatenate(pos)[: idx.shape[0]]
+            if self.unified_position_ids:
+                pos = np.arange(idx.shape[0], dtype=np.int32)
+            idx_all.append(idx), pos_all.append(pos), lens.append(idx.shape[0])
+            out_len.append(segs[-1][1].shape[0] if segs[-1][0] == "resp" else 0)
+        head = "NAR:0:0" if timestep else ("AR:0:0" if q == 0 else f"NAR:{q-1}:{q}")
+        return Plan(np.concatenate(idx_all), np.concatenate(pos_all), lens, out_len, self.cls_names.index(head))
+
+    # ------------------------------------------------------------------------ dense forward
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(_round_up(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _i32(self, arr):
+        return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)).to(self.device, non_blocking=True)
+
+    def forward_dense(self, plan: Plan, out_rows, *, cache=None, want_hidden=False):
+        """Runs the stack on a packed plan; returns fp32 logits (n_out, ld) for the packed row ids
+        in ``out_rows`` (head = plan.head).  cache = (k, v, cache_T, layer_stride, slot, pos0)."""
+        self._prepare()
+        lib = L.load()
+        n_out = int(len(out_rows))
+        vocab = self.cls_tokens[plan.head]
+        ld = _round_up(vocab, 8)
+        idx, pos, cu, rows = self._i32(plan.idx), self._i32(plan.pos), self._i32(plan.cu), self._i32(out_rows)
+        logits = torch.empty((n_out, ld), dtype=torch.float32, device=self.device)
+        hidden = torch.empty((n_out, self.d_model), dtype=self.dtype, device=self.device) if want_hidden else None
+        need = lib.valle_dense_workspace_bytes(self._handle, plan.M, n_out)
+        ws = self._workspace(need)
+        causal = 1  # noncausal_masks=False: every pass is causal (base.py:1233)
+        if self.noncausal_masks:
+            raise NotImplementedError("noncausal_masks=True")
+        if cache is None:
+            kc = vc = slot = pos0 = None
+            cache_T, stride = 0, 0
+        else:
+            kc, vc, cache_T, stride, slot, pos0 = cache
+        L.check(lib.valle_forward_dense(self._handle, L.ptr(idx), L.ptr(pos), L.ptr(cu), plan.B, plan.M, plan.max_T, causal,
+                                        L.ptr(kc), L.ptr(vc), cache_T, stride, L.ptr(slot), L.ptr(pos0),
+                                        L.ptr(rows), n_out, plan.head, L.ptr(logits), ld, L.ptr(hidden),
+                                        L.ptr(ws), ws.numel(), L.stream_ptr(self.device)))
+        return (logits, hidden) if want_hidden else logits
+
+    @staticmethod
+    def tail_rows(plan: Plan, counts):
+        """Packed row ids of the last counts[i] rows of every sequence + per-utterance offsets."""
+        rows, off = [], [0]
+        for i, n in enumerate(counts):
+            end = int(plan.cu[i + 1])
+            rows.append(np.arange(end - n, end, dtype=np.int32))
+            off.append(off[-1] + n)
+        return np.concatenate(rows) if rows else np.zeros(0, np.int32), np.array(off, dtype=np.int32)
+
+    # ----------------------------------------------------------------------------- sampling
+    def sample_params(self, *, temperature=1.0, min_temperature=-1.0, top_k=-100, top_p=1.0, min_p=0.0,
+                      repetition_penalty=1.0, repetition_penalty_decay=0.0, length_penalty=0.0, top_no=1.0,
+                      rep_pen_passes=1, seed=0, offset=0, **other) -> L.SampleParams:
+        """Base.sample's kwargs (base.py:1288-1309) -> the C struct.  Samplers outside the built
+        chain raise instead of being silently ignored."""
+        for k in UNSUPPORTED_SAMPLERS:
+            if other.get(k):
+                raise NotImplementedError(f"sampling option {k!r} is not built on the HIP path")
+        if other.get("mirostat") is not None or other.get("attentions") is not None:
+            raise NotImplementedError("mirostat / entropix sampling are not built on the HIP path")
+        if min_temperature < 0:
+            min_temperature = temperature
+        if abs(float(temperature) - float(min_temperature)) >= 0.001:
+            raise NotImplementedError("dynamic temperature is not built on the HIP path")
+        return L.SampleParams(float(temperature), int(top_k), float(top_p), float(min_p), float(top_no),
+                              float(repetition_penalty), float(repetition_penalty_decay), float(length_penalty),
+                              int(self.stop_token), int(rep_pen_passes), int(seed), int(offset))
+
+    def sample_rows(self, logits, vocab, row_off, prev_list, nar_mode, params):
+        """valle_sample over packed logits rows; row_off = per-utterance row offsets (B+1)."""
+        lib = L.load()
+        B = len(row_off) - 1
+        rows = int(row_off[-1])
+        counts = np.diff(row_off)
+        row_item = np.repeat(np.arange(B, dtype=np.int32), counts)
+        row_in = np.concatenate([np.arange(c, dtype=np.int32) for c in counts]) if rows else np.zeros(0, np.int32)
+        prev = prev_off = prev_len = None
+        if prev_list is not None:
+            pl = [(_np(p) if _np(p).ndim == 1 else _np(p)[:, -1]).astype(np.int32) for p in prev_list]
+            lens = np.array([len(p) for p in pl], dtype=np.int32)
+            prev_off = self._i32(np.concatenate(([0], np.cumsum(lens)[:-1])))
+            prev_len = self._i32(lens)
+            flat = np.concatenate(pl) if lens.sum() else np.zeros(1, np.int32)
+            prev = self._i32(flat)
+        ids = torch.empty(max(rows, 1), dtype=torch.int32, device=self.device)
+        scores = torch.empty(max(rows, 1), dtype=torch.float32, device=self.device)
+        ri, rn = self._i32(row_item), self._i32(row_in)
+        L.check(lib.valle_sample(L.ptr(logits), logits.shape[1], vocab, rows, L.ptr(ri), L.ptr(rn), L.ptr(prev),
+                                 L.ptr(prev_off), L.ptr(prev_len), int(nar_mode), C.byref(params), L.ptr(ids), L.ptr(scores),
+                                 L.stream_ptr(self.device)))
+        return ids[:rows], scores[:rows]
+
+    def cfg_combine(self, pos_logits, neg_logits, vocab, row_off, strength, rescale):
+        lib = L.load()
+        off = self._i32(row_off)
+        L.check(lib.valle_cfg_combine(L.ptr(pos_logits), L.ptr(neg_logits), pos_logits.shape[1], vocab, L.ptr(off),
+                                      len(row_off) - 1, float(strength), float(rescale), L.stream_ptr(self.device)))
+        return pos_logits
+
+
+def _np(t):
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy().astype(np.int64)
+    return np.asarray(t, dtype=np.int64)
