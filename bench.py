@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: RVQ frames/s (all 8 levels) + real-time factor, bf16, batch 16 per GPU.
+
+One "step" = one pass of the hot path over one synthetic batch: AR level-0 generation
+(prefill + KV-cache decode, R frames) followed by the 7 NAR levels -- BASELINE.json configs[1]:
+16 utterances, 80 phonemes, 225 prompt frames (3 s), R = 450 output frames (6 s), random-init
+weights of the repo-default architecture, stop token suppressed through the AR head's bias so
+every implementation generates exactly R frames.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: utterances shard by rank (one independent batch of 16 per GPU, weak scaling); the only
+collective is an RCCL all-gather of the generated codes and per-rank timings.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from vall_e_amd import config as vcfg            # noqa: E402
+from vall_e_amd.models import get_model          # noqa: E402
+from vall_e_amd.synth import synth_batch         # noqa: E402
+from vall_e_amd.weights import synth_state_dict  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FRAME_RATE = 75.0
+
+
+def decode_step_bytes(cfg, B, ctx):
+    """Algorithmic HBM bytes of one AR decode step, bf16, KV cache."""
+    d, L, ff = cfg.dim, cfg.layers, cfg.dim * cfg.ffn
+    weights = L * (4 * d * d + 3 * d * ff) * 2
+    head = (cfg.audio_tokens + 1) * d * 2 + (cfg.audio_tokens + 1) * 4
+    norms = (2 * L + 1) * d * 2
+    kv_row = L * 2 * d * 2
+    return weights + head + norms + sum(c * kv_row for c in ctx) + B * kv_row + B * d * 2
+
+
+def cpu_baseline(cfg, sd, phns, proms, langs, R):
+    """The oracle (CPU restatement of the reference, fp32, no KV cache like the reference) timed
+    on this box's host cores on a bounded sample; extrapolated linearly in context."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import valle_oracle as vo
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    o = vo.Oracle(cfg, {k: v for k, v in sd.items()}, dtype=torch.float32)
+    B = len(phns)
+    empty = [torch.zeros(0, dtype=torch.int64) for _ in range(B)]
+    plans = o._plans(phns, langs, proms, empty, 0)
+    ctx0 = plans[0].pos.shape[0]
+    t0 = time.perf_counter()
+    n_ar = 2
+    with torch.inference_mode():
+        for _ in range(n_ar):
+            o.forward(plans, rows=[1] * B)
+    t_ar = (time.perf_counter() - t0) / n_ar
+    Bn = 4                                                     # one NAR level on a quarter batch
+    g = torch.Generator().manual_seed(3)
+    resp = [torch.randint(0, 1024, (R, 1), generator=g) for _ in range(Bn)]
+    nplans = o._plans(phns[:Bn], langs[:Bn], proms[:Bn], resp, 1)
+    t0 = time.perf_counter()
+    with torch.inference_mode():
+        o.forward(nplans, rows=[R] * Bn)
+    t_nar = (time.perf_counter() - t0) * (B / Bn)
+    # recompute AR: step n costs ~ t_ar * (ctx0 + n) / ctx0 (linear-in-context extrapolation)
+    ar_total = sum(t_ar * (ctx0 + n) / ctx0 for n in range(R))
+    total = ar_total + 7 * t_nar
+    return {
+        "value": round(B * R / total, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": (f"oracle (fp32 restatement, full recompute per AR step as the reference does): {n_ar} AR steps "
+                   f"at ctx {ctx0} B={B} = {t_ar:.2f} s/step, one NAR level at T={ctx0 + R} on {Bn}/{B} of the batch "
+                   f"= {t_nar:.2f} s/level scaled; whole job extrapolated linearly in context "
+                   f"({R} AR steps + 7 NAR levels = {total:.0f} s)"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--frames", type=int, default=450)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = vcfg.repo_default_model()
+    B, R = args.batch, args.frames
+    sd = synth_state_dict(cfg, 1234, stop_bias=-30000.0)
+    model = get_model(cfg).load_state_dict(sd).to(dev, torch.bfloat16)
+    phns, proms, langs = synth_batch(1234 + rank, B, n_phn=80, n_prom=225)
+    tasks = ["tts"] * B
+    prof = []
+
+    def step(profile=None):
+        codes = model(task_list=tasks, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=R,
+                      temperature=0.0, step_chunk=R, profile=profile)
+        full = model(task_list=tasks, phns_list=phns, proms_list=proms, lang_list=langs,
+                     resps_list=codes, temperature=0.0)
+        out = torch.stack([f.to(torch.int16) for f in full])            # (B, R, 8)
+        if dist is not None:
+            gathered = [torch.empty_like(out) for _ in range(world)]
+            dist.all_gather(gathered, out)                              # RCCL: codes of every rank
+        return out
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out = step()
+    assert out.shape == (B, R, 8), out.shape
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(profile=prof)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames = world * B * R * args.steps
+    ms_per_step = elapsed / args.steps * 1e3
+    # roofline of the dominant kernel group: the AR decode step (weights + KV cache streamed once)
+    dec_ms, dec_steps, dec_bytes = 0.0, 0, 0.0
+    for e0, e1, n, ctx0 in prof:
+        dec_ms += e0.elapsed_time(e1)
+        dec_steps += n
+        for j in range(n):
+            dec_bytes += decode_step_bytes(cfg, B, [c + j for c in ctx0])
+    roofline = None
+    if dec_steps:
+        achieved = dec_bytes / (dec_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel": "AR decode step (valle_ar_decode: all kernels of one step)",
+                    "us_per_decode_step": round(dec_ms * 1e3 / dec_steps, 2),
+                    "algorithmic_bytes_per_step": int(dec_bytes / dec_steps)}
+    if rank == 0:
+        line = {
+            "metric": "RVQ frames/sec (all levels)", "value": round(frames / elapsed, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[1]: AR KV-cache decode + 7 NAR levels, repo-default ar+nar llama (d=1024, L=12), "
+                                   f"batch {B}/GPU, 80 phonemes, 225 prompt frames, {R} output frames, greedy",
+                       "global_batch": world * B, "frames_per_utterance": R, "parallelism": f"utterance-sharded x{world}"},
+            "rtf": round((elapsed / args.steps) / (R / FRAME_RATE), 5),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, phns, proms, langs, R)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

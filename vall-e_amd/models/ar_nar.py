@@ -80,6 +80,7 @@ class AR_NAR(Base):
         max_duration = kw.get("max_duration", 500)
         step_chunk = int(kw.pop("step_chunk", 32))
         return_logits = kw.pop("return_logits", False)
+        prof = kw.pop("profile", None)      # list: receives (start_event, end_event, n_steps, ctx_len_host) per decode chunk
         prefix_context = kw.get("prefix_context", None)
         sp = self.sample_params(**kw)
         B = len(phns_list)
@@ -145,8 +146,14 @@ class AR_NAR(Base):
                 n = min(step_chunk, n_steps - done)
                 lg_out = torch.empty((n, B, ld), dtype=torch.float32, device=dev) if return_logits else None
                 sp.offset = done
+                if prof is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 L.check(lib.valle_ar_decode(self._handle, C.byref(st), C.byref(sp), n, L.ptr(lg_out), ld,
                                             L.ptr(ws), ws.numel(), stream))
+                if prof is not None:
+                    e1.record()
+                    prof.append((e0, e1, n, [int(t) + done for t in plan.lens]))
                 if return_logits:
                     all_logits.extend(lg_out[j, :, :V] for j in range(n))
                 done += n
