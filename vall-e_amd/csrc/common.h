@@ -75,6 +75,7 @@ struct valle_model {
     int n_cls;
     const void** head_w;
     const float** head_b;
+    const void** head_p;
     int32_t* head_n;
 };
 
@@ -102,6 +103,7 @@ struct DecArgs {
     // QKV epilogue: RoPE + KV-cache append
     const float* rope; const int32_t* pos; const int32_t* ctx_len; const int32_t* slot;
     bf16* kc; bf16* vc; int cache_T; int H; int d;
+    int dbg;   // dev ablation switches (0 in production)
 };
 int valle_dec_linear_bf16(const DecArgs& a, int epilogue, hipStream_t s);
 
@@ -111,3 +113,5 @@ extern "C" int valle_attn_prefill_rowwise(const void* qkv, void* out, const int3
 int valle_attn_decode_launch(const void* qkv, const void* kcache, const void* vcache, const int32_t* ctx_len,
                              const int32_t* cache_slot, void* out, int B, int H, int Dh, int cache_T,
                              int ctx_extra, int dtype, void* stream);
+int valle_attn_flash_bf16(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int max_T, int H, int causal,
+                          hipStream_t s);

@@ -5,14 +5,15 @@
 
 extern "C" int valle_attn_prefill(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int M, int max_T,
                                   int H, int Dh, int causal, int dtype, void* stream) {
-    (void)max_T;
+    if (dtype == VALLE_BF16 && Dh == 64 && max_T > 0 && qkv && out && cu_seqlens && M > 0)
+        return valle_attn_flash_bf16(qkv, out, cu_seqlens, B, max_T, H, causal, (hipStream_t)stream);
     return valle_attn_prefill_rowwise(qkv, out, cu_seqlens, B, M, H, Dh, causal, dtype, stream);
 }
 
 extern "C" int valle_model_create(const valle_config* cfg, const void* emb, const float* rope,
                                   const valle_layer_weights* layers_host, const void* final_norm,
                                   int n_cls, const void* const* head_w_host, const float* const* head_b_host,
-                                  const int32_t* head_n_host, valle_model** out) {
+                                  const int32_t* head_n_host, const void* const* head_p_host, valle_model** out) {
     VALLE_REQUIRE(cfg && emb && rope && layers_host && final_norm && out, VALLE_E_ARG, "valle_model_create: null pointer");
     VALLE_REQUIRE(cfg->n_heads > 0 && cfg->d_model % cfg->n_heads == 0 && cfg->d_model / cfg->n_heads == 64,
                   VALLE_E_UNSUPPORTED, "valle_model_create: head_dim must be 64 (d_model %d, heads %d)", cfg->d_model, cfg->n_heads);
@@ -27,10 +28,12 @@ extern "C" int valle_model_create(const valle_config* cfg, const void* emb, cons
     m->head_w = (const void**)malloc(sizeof(void*) * (n_cls > 0 ? n_cls : 1));
     m->head_b = (const float**)malloc(sizeof(float*) * (n_cls > 0 ? n_cls : 1));
     m->head_n = (int32_t*)malloc(sizeof(int32_t) * (n_cls > 0 ? n_cls : 1));
+    m->head_p = (const void**)malloc(sizeof(void*) * (n_cls > 0 ? n_cls : 1));
     for (int k = 0; k < n_cls; ++k) {
         m->head_w[k] = head_w_host[k];
         m->head_b[k] = head_b_host ? head_b_host[k] : nullptr;
         m->head_n[k] = head_n_host[k];
+        m->head_p[k] = head_p_host ? head_p_host[k] : nullptr;
     }
     *out = m;
     return VALLE_OK;
@@ -38,7 +41,7 @@ extern "C" int valle_model_create(const valle_config* cfg, const void* emb, cons
 
 extern "C" void valle_model_destroy(valle_model* m) {
     if (!m) return;
-    free(m->layers); free((void*)m->head_w); free((void*)m->head_b); free(m->head_n); free(m);
+    free(m->layers); free((void*)m->head_w); free((void*)m->head_b); free(m->head_n); free((void*)m->head_p); free(m);
 }
 
 // ------------------------------------------------------------------ small helpers
@@ -184,7 +187,8 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
     VALLE_REQUIRE(ws.ok, VALLE_E_WORKSPACE, "valle_ar_decode: workspace %zu B too small (need %zu)", workspace_bytes,
                   valle_decode_workspace_bytes(m, B));
     hipStream_t s = (hipStream_t)stream;
-    const bool fused = (dt == VALLE_BF16) && B <= 32 && (d == 256 || d == 1024) && (f == 256 || f == 1024 || f == 4096);
+    const bool fused = (dt == VALLE_BF16) && B <= 32 && (d == 256 || d == 1024) && (f == 256 || f == 1024 || f == 4096) &&
+                       m->layers[0].p_qkv && m->layers[0].p_o && m->layers[0].p_gu && m->layers[0].p_down && m->head_p[st->head];
     int rc;
     for (int step = 0; step < n_steps; ++step) {
         float* lg = logits_out ? logits_out + (size_t)step * B * ld_logits : lg_ws;
@@ -200,21 +204,21 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
             void* vc = (char*)st->vcache + (size_t)l * st->cache_layer_stride * es;
             if (fused) {
                 DecArgs a{};
-                a.x = (const bf16*)x; a.norm_w = (const bf16*)w.ln1; a.eps = c.rms_eps; a.W = (const bf16*)w.w_qkv;
+                a.x = (const bf16*)x; a.norm_w = (const bf16*)w.ln1; a.eps = c.rms_eps; a.W = (const bf16*)w.p_qkv;
                 a.out = qkv; a.ldo = 3 * d; a.B = B; a.N = 3 * d; a.K = d;
                 a.rope = m->rope; a.pos = pos; a.ctx_len = st->ctx_len; a.slot = st->cache_slot;
                 a.kc = (bf16*)kc; a.vc = (bf16*)vc; a.cache_T = st->cache_T; a.H = H; a.d = d;
                 RUN(valle_dec_linear_bf16(a, DEC_EPI_QKV, s));
                 RUN(valle_attn_decode_launch(qkv, kc, vc, st->ctx_len, st->cache_slot, att, B, H, Dh, st->cache_T, 1, dt, s));
                 DecArgs o{};
-                o.x = (const bf16*)att; o.W = (const bf16*)w.w_o; o.resid = (const bf16*)x; o.out = x; o.ldo = d; o.B = B; o.N = d; o.K = d;
+                o.x = (const bf16*)att; o.W = (const bf16*)w.p_o; o.resid = (const bf16*)x; o.out = x; o.ldo = d; o.B = B; o.N = d; o.K = d;
                 RUN(valle_dec_linear_bf16(o, VALLE_EPI_RESID, s));
                 DecArgs g{};
-                g.x = (const bf16*)x; g.norm_w = (const bf16*)w.ln2; g.eps = c.rms_eps; g.W = (const bf16*)w.w_gu;
+                g.x = (const bf16*)x; g.norm_w = (const bf16*)w.ln2; g.eps = c.rms_eps; g.W = (const bf16*)w.p_gu;
                 g.out = ff; g.ldo = f; g.B = B; g.N = 2 * f; g.K = d;
                 RUN(valle_dec_linear_bf16(g, VALLE_EPI_GEGLU, s));
                 DecArgs dn{};
-                dn.x = (const bf16*)ff; dn.W = (const bf16*)w.w_down; dn.resid = (const bf16*)x; dn.out = x; dn.ldo = d; dn.B = B; dn.N = d; dn.K = f;
+                dn.x = (const bf16*)ff; dn.W = (const bf16*)w.p_down; dn.resid = (const bf16*)x; dn.out = x; dn.ldo = d; dn.B = B; dn.N = d; dn.K = f;
                 RUN(valle_dec_linear_bf16(dn, VALLE_EPI_RESID, s));
             } else {
                 RUN(valle_rmsnorm(x, w.ln1, h, B, d, c.rms_eps, dt, s));
@@ -229,7 +233,7 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
         }
         if (fused) {
             DecArgs hd{};
-            hd.x = (const bf16*)x; hd.norm_w = (const bf16*)m->final_norm; hd.eps = c.rms_eps; hd.W = (const bf16*)m->head_w[st->head];
+            hd.x = (const bf16*)x; hd.norm_w = (const bf16*)m->final_norm; hd.eps = c.rms_eps; hd.W = (const bf16*)m->head_p[st->head];
             hd.bias = m->head_b[st->head]; hd.out = lg; hd.ldo = ldl; hd.B = B; hd.N = st->vocab; hd.K = d;
             RUN(valle_dec_linear_bf16(hd, VALLE_EPI_F32OUT, s));
         } else {

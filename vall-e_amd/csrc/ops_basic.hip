@@ -257,21 +257,40 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(AttnRowArgs a) {
     for (int e = 0; e < VEC; ++e) o[e] = 0.f;
 
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
-    for (int k0 = wave * 8 + g; k0 < n_keys + 0; k0 += 32) {
-        const vec_t kv = *reinterpret_cast<const vec_t*>(kb + (size_t)k0 * a.kv_row_stride + sub * VEC);
-        const vec_t vv = *reinterpret_cast<const vec_t*>(vb + (size_t)k0 * a.kv_row_stride + sub * VEC);
-        float s = 0.f;
+    constexpr int UN = 4;   // keys per group per iteration: 2*UN 16-byte loads in flight per lane
+    for (int k0 = wave * 8 + g; k0 < n_keys; k0 += 32 * UN) {
+        vec_t kv[UN], vv[UN];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) s = fmaf(q[e], to_f32<T>(kv[e]), s);
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
-        const float mn = fmaxf(m, s);
-        const float alpha = expf(m - mn);   // m = -inf on the first key: exp(-inf) = 0
-        const float p = expf(s - mn);
-        l = l * alpha + p;
+        for (int u = 0; u < UN; ++u) {
+            int key = k0 + 32 * u;
+            key = key < n_keys ? key : n_keys - 1;       // clamp: the load stays unconditional
+            kv[u] = *reinterpret_cast<const vec_t*>(kb + (size_t)key * a.kv_row_stride + sub * VEC);
+            vv[u] = *reinterpret_cast<const vec_t*>(vb + (size_t)key * a.kv_row_stride + sub * VEC);
+        }
+        float s[UN];
+        float mn = m;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) o[e] = o[e] * alpha + p * to_f32<T>(vv[e]);
+        for (int u = 0; u < UN; ++u) {
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) t = fmaf(q[e], to_f32<T>(kv[u][e]), t);
+            t += __shfl_xor(t, 1, 64);
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 4, 64);
+            s[u] = (k0 + 32 * u < n_keys) ? t : -INFINITY;
+            mn = fmaxf(mn, s[u]);
+        }
+        const float alpha = expf(m - mn);    // m = -inf on the first pass: exp(-inf) = 0 (s[0] is always valid)
+        l *= alpha;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] *= alpha;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const float p = expf(s[u] - mn);
+            l += p;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = fmaf(p, to_f32<T>(vv[u][e]), o[e]);
+        }
         m = mn;
     }
     // merge the 8 groups of the wave (lanes with equal `sub`)

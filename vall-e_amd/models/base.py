@@ -188,11 +188,16 @@ class Base:
             b[f"down{l}"] = sd[p + "mlp.down_proj.weight"].to(dev, dt).contiguous()
             b[f"ln1_{l}"] = sd[p + "input_layernorm.weight"].to(dev, dt).contiguous()
             b[f"ln2_{l}"] = sd[p + "post_attention_layernorm.weight"].to(dev, dt).contiguous()
+            packed = [None] * 4
+            if dt == torch.bfloat16 and d % 64 == 0:
+                for j, n in enumerate(("qkv", "o", "gu", "down")):
+                    b[f"p_{n}{l}"] = pack_stream_order(b[f"{n}{l}"])
+                    packed[j] = b[f"p_{n}{l}"].data_ptr()
             layers[l] = L.LayerWeights(b[f"ln1_{l}"].data_ptr(), b[f"qkv{l}"].data_ptr(), b[f"o{l}"].data_ptr(),
-                                       b[f"ln2_{l}"].data_ptr(), b[f"gu{l}"].data_ptr(), b[f"down{l}"].data_ptr())
+                                       b[f"ln2_{l}"].data_ptr(), b[f"gu{l}"].data_ptr(), b[f"down{l}"].data_ptr(), *packed)
         b["norm"] = sd["model.norm.weight"].to(dev, dt).contiguous()
         n_cls = len(self.cls_tokens)
-        hw, hb, hn = (C.c_void_p * n_cls)(), (C.c_void_p * n_cls)(), (C.c_int32 * n_cls)()
+        hw, hb, hn, hp = (C.c_void_p * n_cls)(), (C.c_void_p * n_cls)(), (C.c_int32 * n_cls)(), (C.c_void_p * n_cls)()
         for k in range(n_cls):
             b[f"hw{k}"] = sd[f"classifiers.proj.{k}.weight"].to(dev, dt).contiguous()
             hw[k] = b[f"hw{k}"].data_ptr()
@@ -203,12 +208,16 @@ class Base:
             else:
                 hb[k] = None
             hn[k] = self.cls_tokens[k]
+            hp[k] = None
+            if dt == torch.bfloat16 and k == 0:      # the AR head is the one the decode loop streams
+                b[f"hp{k}"] = pack_stream_order(b[f"hw{k}"])
+                hp[k] = b[f"hp{k}"].data_ptr()
         cfg = L.Config(d, H, self.n_layers, ff, L.dtype_code(dt), 1e-6, self.max_position_embeddings)
         handle = C.c_void_p()
         L.check(lib.valle_model_create(C.byref(cfg), L.ptr(b["emb"]), L.ptr(b["rope"]), layers, L.ptr(b["norm"]), n_cls,
-                                       hw, hb, hn, C.byref(handle)))
+                                       hw, hb, hn, hp, C.byref(handle)))
         self._handle = handle
-        self._keep = [layers, hw, hb, hn]
+        self._keep = [layers, hw, hb, hn, hp]
 
     # -------------------------------------------------------------------- sequence planning
     def plan(self, phns_list, lang_list, proms_list, resps_list, quant_level, *, timestep=False) -> Plan:
@@ -374,6 +383,16 @@ class Base:
         L.check(lib.valle_cfg_combine(L.ptr(pos_logits), L.ptr(neg_logits), pos_logits.shape[1], vocab, L.ptr(off),
                                       len(row_off) - 1, float(strength), float(rescale), L.stream_ptr(self.device)))
         return pos_logits
+
+
+def pack_stream_order(w: torch.Tensor) -> torch.Tensor:
+    """[N][K] -> [ceil(N/16)][K/64][2][64 lanes][8] (valle_hip.h, valle_layer_weights.p_*)."""
+    N, K = w.shape
+    Np = _round_up(N, 16)
+    if Np != N:
+        w = torch.cat([w, w.new_zeros(Np - N, K)])
+    t = w.reshape(Np // 16, 16, K // 64, 2, 4, 8)        # nt, fr, ks, half, fq, j
+    return t.permute(0, 2, 3, 4, 1, 5).contiguous().reshape(-1)
 
 
 def _np(t):
