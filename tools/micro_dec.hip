@@ -44,7 +44,7 @@ int main() {
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         const double us = ms * 1e3 / (reps * L);
-        printf("%-34s %7.2f us/launch  %6.2f TB/s\n", name, us, mb / us * 1e-6 * 1e6 / 1e6);
+        printf("%-34s %7.2f us/launch  %6.2f TB/s\n", name, us, mb / us);
     };
     timeit("stream 16.8MB (512 blk x 32KB)", 16.78, [&](int l) { stream_kernel<32768><<<512, 256, 0, s>>>((const uint4*)wgu[l], sink); });
     timeit("stream 16.8MB (1024 blk x 16KB)", 16.78, [&](int l) { stream_kernel<16384><<<1024, 256, 0, s>>>((const uint4*)wgu[l], sink); });
@@ -59,6 +59,19 @@ int main() {
     timeit("dec gate/up GEGLU (16.8MB)", 16.78, [&](int l) { valle_dec_linear_bf16(mk(x, nw, wgu[l], nullptr, ff, f, 2 * f, d), VALLE_EPI_GEGLU, s); });
     timeit("dec down RESID (8.4MB)", 8.39, [&](int l) { valle_dec_linear_bf16(mk(ff, nullptr, wdn[l], x, x, d, d, f), VALLE_EPI_RESID, s); });
     timeit("dec o_proj RESID (2MB)", 2.10, [&](int l) { valle_dec_linear_bf16(mk(h, nullptr, wo[l], x, x, d, d, d), VALLE_EPI_RESID, s); });
+    {   // decode attention over a KV cache set larger than the Infinity Cache
+        const int H = 16, CT = 768, NL = 6;
+        const size_t per = (size_t)B * H * CT * 64;
+        bf16 *kc, *vc, *qkvb, *att; int32_t* ctx;
+        CK(hipMalloc(&kc, per * NL * 2)); CK(hipMalloc(&vc, per * NL * 2)); CK(hipMemset(kc, 0x3c, per * NL * 2)); CK(hipMemset(vc, 0x3c, per * NL * 2));
+        CK(hipMalloc(&qkvb, B * 3 * d * 2)); CK(hipMemset(qkvb, 0x3c, B * 3 * d * 2)); CK(hipMalloc(&att, B * d * 2));
+        CK(hipMalloc(&ctx, B * 4));
+        for (int cl : {311, 536, 760}) {
+            std::vector<int32_t> hc(B, cl); CK(hipMemcpy(ctx, hc.data(), B * 4, hipMemcpyHostToDevice));
+            char nm[64]; snprintf(nm, sizeof nm, "attn decode ctx=%d", cl);
+            timeit(nm, (double)B * H * cl * 256 / 1e6, [&](int l) { valle_attn_decode_launch(qkvb, kc + per * (l % NL), vc + per * (l % NL), ctx, nullptr, att, B, H, 64, CT, 0, VALLE_BF16, s); });
+        }
+    }
     printf("last error: %s\n", valle_last_error());
     return 0;
 }

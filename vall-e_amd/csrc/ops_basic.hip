@@ -5,6 +5,7 @@
 //   attn_rowwise   models/arch/llama.py:448-456 (one query row per workgroup; parity path + decode)
 #include "common.h"
 #include <stdarg.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 void valle_set_error(const char* fmt, ...) {
@@ -221,8 +222,8 @@ struct AttnRowArgs {
     int ctx_extra;                                 // decode: keys = ctx_len + ctx_extra
 };
 
-template <typename T, bool DECODE>
-__global__ __launch_bounds__(256) void attn_rowwise_kernel(AttnRowArgs a) {
+template <typename T, bool DECODE, int NW, int UN>
+__global__ __launch_bounds__(NW * 64) void attn_rowwise_kernel(AttnRowArgs a) {
     constexpr int DH = 64;
     constexpr int VEC = 8;
     const int row = blockIdx.x, h = blockIdx.y;
@@ -257,12 +258,12 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(AttnRowArgs a) {
     for (int e = 0; e < VEC; ++e) o[e] = 0.f;
 
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
-    constexpr int UN = 4;   // keys per group per iteration: 2*UN 16-byte loads in flight per lane
-    for (int k0 = wave * 8 + g; k0 < n_keys; k0 += 32 * UN) {
+    // UN keys per group per iteration: 2*UN 16-byte loads in flight per lane
+    for (int k0 = wave * 8 + g; k0 < n_keys; k0 += NW * 8 * UN) {
         vec_t kv[UN], vv[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            int key = k0 + 32 * u;
+            int key = k0 + NW * 8 * u;
             key = key < n_keys ? key : n_keys - 1;       // clamp: the load stays unconditional
             kv[u] = *reinterpret_cast<const vec_t*>(kb + (size_t)key * a.kv_row_stride + sub * VEC);
             vv[u] = *reinterpret_cast<const vec_t*>(vb + (size_t)key * a.kv_row_stride + sub * VEC);
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(AttnRowArgs a) {
             t += __shfl_xor(t, 1, 64);
             t += __shfl_xor(t, 2, 64);
             t += __shfl_xor(t, 4, 64);
-            s[u] = (k0 + 32 * u < n_keys) ? t : -INFINITY;
+            s[u] = (k0 + NW * 8 * u < n_keys) ? t : -INFINITY;
             mn = fmaxf(mn, s[u]);
         }
         const float alpha = expf(m - mn);    // m = -inf on the first pass: exp(-inf) = 0 (s[0] is always valid)
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(AttnRowArgs a) {
         }
         m = mn;
     }
-    __shared__ float sm_m[4], sm_l[4], sm_o[4][DH];
+    __shared__ float sm_m[NW], sm_l[NW], sm_o[NW][DH];
     if (g == 0) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) sm_o[wave][sub * VEC + e] = o[e];
@@ -316,10 +317,12 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(AttnRowArgs a) {
     }
     __syncthreads();
     if (threadIdx.x < DH) {
-        float mm = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
+        float mm = sm_m[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) mm = fmaxf(mm, sm_m[w]);
         float num = 0.f, den = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const float sc = (sm_m[w] == -INFINITY) ? 0.f : expf(sm_m[w] - mm);
             num += sm_o[w][threadIdx.x] * sc;
             den += sm_l[w] * sc;
@@ -342,8 +345,8 @@ extern "C" int valle_attn_prefill_rowwise(const void* qkv, void* out, const int3
     a.cu = cu_seqlens; a.out = out; a.out_row_stride = d; a.causal = causal; a.B = B;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(M, H);
-    if (dtype == VALLE_BF16) attn_rowwise_kernel<bf16, false><<<grid, 256, 0, s>>>(a);
-    else if (dtype == VALLE_F32) attn_rowwise_kernel<float, false><<<grid, 256, 0, s>>>(a);
+    if (dtype == VALLE_BF16) attn_rowwise_kernel<bf16, false, 4, 4><<<grid, 256, 0, s>>>(a);
+    else if (dtype == VALLE_F32) attn_rowwise_kernel<float, false, 4, 4><<<grid, 256, 0, s>>>(a);
     else VALLE_REQUIRE(false, VALLE_E_ARG, "valle_attn_prefill: unknown dtype %d", dtype);
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
@@ -364,8 +367,14 @@ int valle_attn_decode_launch(const void* qkv, const void* kcache, const void* vc
     a.out = out; a.out_row_stride = d; a.causal = 1; a.B = B; a.ctx_extra = ctx_extra;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(B, H);
-    if (dtype == VALLE_BF16) attn_rowwise_kernel<bf16, true><<<grid, 256, 0, s>>>(a);
-    else if (dtype == VALLE_F32) attn_rowwise_kernel<float, true><<<grid, 256, 0, s>>>(a);
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("VALLE_ATTN_VARIANT"); variant = e ? atoi(e) : 0; }
+    if (dtype == VALLE_BF16 && variant == 1) attn_rowwise_kernel<bf16, true, 4, 4><<<grid, 256, 0, s>>>(a);
+    else if (dtype == VALLE_BF16 && variant == 2) attn_rowwise_kernel<bf16, true, 4, 8><<<grid, 256, 0, s>>>(a);
+    else if (dtype == VALLE_BF16 && variant == 3) attn_rowwise_kernel<bf16, true, 16, 4><<<grid, 1024, 0, s>>>(a);
+    else if (dtype == VALLE_BF16 && variant == 4) attn_rowwise_kernel<bf16, true, 8, 2><<<grid, 512, 0, s>>>(a);
+    else if (dtype == VALLE_BF16) attn_rowwise_kernel<bf16, true, 8, 8><<<grid, 512, 0, s>>>(a);
+    else if (dtype == VALLE_F32) attn_rowwise_kernel<float, true, 8, 4><<<grid, 512, 0, s>>>(a);
     else VALLE_REQUIRE(false, VALLE_E_ARG, "valle_attn_decode: unknown dtype %d", dtype);
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
