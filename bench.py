@@ -122,8 +122,9 @@ def main():
                      resps_list=codes, temperature=0.0)
         out = torch.stack([f.to(torch.int16) for f in full])            # (B, R, 8)
         if dist is not None:
-            gathered = [torch.empty_like(out) for _ in range(world)]
-            dist.all_gather(gathered, out)                              # RCCL: codes of every rank
+            raw = out.view(torch.uint8)                                 # RCCL has no int16: ship the bytes
+            gathered = [torch.empty_like(raw) for _ in range(world)]
+            dist.all_gather(gathered, raw)                              # RCCL: codes of every rank
         return out
 
     def fence():

@@ -330,3 +330,32 @@ def test_flash_attention_bf16_vs_fp64(gpu_device, lens, causal):
     got = out.double().cpu()
     assert (got - want).abs().max().item() < 3e-2
     assert ((got - want).norm() / want.norm()).item() < 8e-3
+
+
+# ------------------------------------------------------------------------------ caller (a21)
+def test_tts_batched_inference_matches_oracle(gpu_device):
+    """TTS.batched_inference (sort by length, chunks of batch_size, AR then NAR per chunk --
+    vall_e/inference.py:288-346) returns, in the caller's order, the codes the oracle produces when
+    fed the same chunks; also the 2-rank shard of the same call covers every utterance once."""
+    from vall_e_amd.inference import TTS, chunk, shard_utterances, sort_key
+    from vall_e_amd.synth import synth_batch
+    phns, proms, langs = synth_batch(77, 5, n_phn=14, n_prom=24, ragged=True)
+    tts = TTS(config=model_cfg("tiny"), device="cuda:0", dtype=torch.float32, state_dict=synth_weights("tiny"))
+    got = tts.batched_inference(list(phns), list(proms), list(langs), batch_size=2, max_duration=6, temperature=0.0)
+    o = oracle("tiny")
+    lens = [sort_key(t, p) for t, p in zip(phns, proms)]
+    order = shard_utterances(lens, 1)[0]
+    want = {}
+    for idx in chunk(order, 2):
+        a = [phns[i] for i in idx], [proms[i] for i in idx], [langs[i] for i in idx]
+        full = o.nar(*a, o.ar(*a, max_duration=6, temperature=0.0), temperature=0.0)
+        want.update(zip(idx, full))
+    for i in range(5):
+        np.testing.assert_array_equal(got[i].cpu().numpy(), want[i].numpy())
+    seen = []
+    for r in range(2):
+        codes, mine = tts.batched_inference(list(phns), list(proms), list(langs), batch_size=4, max_duration=6,
+                                            temperature=0.0, rank=r, world_size=2)
+        assert len(codes) == len(mine)
+        seen += mine
+    assert sorted(seen) == list(range(5))

@@ -1,0 +1,148 @@
+"""``TTS``: the reference's API façade for the batched path, on pre-tokenised inputs.
+
+Mirrors ``vall_e.inference.TTS`` (reference inference.py:37-597) for what sits on the hot path:
+``batched_inference`` sorts utterances by ``len(text) + 1 + len(prompt) + 1`` (inference.py:288-293),
+cuts chunks of ``batch_size`` (:296-311) and runs AR then NAR, or (NAR-len) demasking then NAR,
+per chunk (:326-346).  The reference's text front end (phonemizer) and codec (EnCodec/Vocos) are
+out of scope: texts are phoneme-id tensors, references are ``(P, 8)`` code tensors, and the
+result is the list of ``(R, 8)`` code tensors the reference would hand to ``qnt.decode``
+(inference.py:350-355), in the caller's order.
+
+Multi-GPU: utterances are independent, so ``shard_utterances`` deals the length-sorted list
+round-robin to ranks and ``gather_codes`` returns every rank's codes with one all-gather
+(RCCL on GPUs, gloo in the CPU tests) -- the only collective of the path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .config import Model as ModelConfig, repo_default_model
+from .models import get_model
+
+
+def sort_key(text, prom):
+    """inference.py:288."""
+    return int(text.shape[0]) + 1 + (int(prom.shape[0]) if prom is not None else 0) + 1
+
+
+def shard_utterances(lengths, world_size):
+    """Length-sorted utterance indices dealt round-robin: rank r gets sorted[r::world_size], so every
+    rank sees the same mix of short and long utterances."""
+    order = sorted(range(len(lengths)), key=lambda i: (lengths[i], i))
+    return [order[r::world_size] for r in range(world_size)]
+
+
+def chunk(indices, batch_size):
+    """inference.py:296-311."""
+    batch_size = max(1, int(batch_size))
+    return [indices[i:i + batch_size] for i in range(0, len(indices), batch_size)]
+
+
+def pack_codes(codes, r_max, levels=8):
+    """list of (R_i, levels) integer tensors -> (int16 [n, r_max, levels], int32 [n] lengths)."""
+    block = torch.zeros((len(codes), r_max, levels), dtype=torch.int16)
+    lens = torch.zeros(len(codes), dtype=torch.int32)
+    for i, c in enumerate(codes):
+        c = c.detach().to("cpu", torch.int16)
+        if c.shape[0] > r_max:
+            raise ValueError(f"utterance {i}: {c.shape[0]} frames exceed the gather block ({r_max})")
+        block[i, : c.shape[0]] = c
+        lens[i] = c.shape[0]
+    return block, lens
+
+
+def gather_codes(local_codes, local_indices, n_total, r_max, group=None, device=None):
+    """All ranks' codes in the caller's utterance order.  One all-gather of a fixed-size padded block
+    per rank (codes int16 [n_loc_max][r_max][8], lengths, utterance ids); every rank returns the list."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        out = [None] * n_total
+        for i, c in zip(local_indices, local_codes):
+            out[i] = c
+        return out
+    n_loc_max = (n_total + world - 1) // world
+    block, lens = pack_codes(local_codes, r_max)
+    pad = n_loc_max - block.shape[0]
+    ids = torch.full((n_loc_max,), -1, dtype=torch.int32)
+    ids[: len(local_indices)] = torch.tensor(local_indices, dtype=torch.int32)
+    if pad:
+        block = torch.cat([block, block.new_zeros((pad,) + tuple(block.shape[1:]))])
+        lens = torch.cat([lens, lens.new_zeros(pad)])
+    dev = device if device is not None else "cpu"
+    block, lens, ids = block.to(dev), lens.to(dev), ids.to(dev)
+    block = block.view(torch.uint8)          # neither gloo nor RCCL carries int16: ship the bytes
+    blocks = [torch.empty_like(block) for _ in range(world)]
+    all_lens = [torch.empty_like(lens) for _ in range(world)]
+    all_ids = [torch.empty_like(ids) for _ in range(world)]
+    dist.all_gather(blocks, block, group=group)
+    dist.all_gather(all_lens, lens, group=group)
+    dist.all_gather(all_ids, ids, group=group)
+    out = [None] * n_total
+    for b, l, u in zip(blocks, all_lens, all_ids):
+        b = b.view(torch.int16)
+        for j in range(n_loc_max):
+            i = int(u[j])
+            if i >= 0:
+                out[i] = b[j, : int(l[j])].clone()
+    return out
+
+
+class TTS:
+    """Constructor keeps the reference's keyword names (inference.py:38); ``config`` is a
+    ``vall_e_amd.config.Model`` (or None for the repo default, data/config.yaml) and ``state_dict`` the
+    reference's parameter names -> tensors (random-init synthetic weights if omitted)."""
+
+    def __init__(self, config=None, lora=None, device=None, amp=None, dtype=None, attention=None, state_dict=None, seed=1234):
+        if lora is not None:
+            raise NotImplementedError("LoRA is outside the built path")
+        if attention not in (None, "auto", "valle_hip"):
+            raise NotImplementedError(f"attention backend {attention!r}: the HIP path has one attention implementation")
+        self.config = config if isinstance(config, ModelConfig) else repo_default_model()
+        self.device = torch.device(device if device is not None else "cuda")
+        self.dtype = dtype if dtype is not None else torch.float32        # data/config.yaml:118 weight_dtype float32
+        self.amp = bool(amp)
+        self.batch_size = 16                                               # config.py:856
+        if state_dict is None:
+            from .weights import synth_state_dict
+            state_dict = synth_state_dict(self.config, seed)
+        self.model = get_model(self.config).load_state_dict(state_dict).to(self.device, self.dtype)
+
+    def modality(self, modality):
+        """inference.py:210-214: 'auto' resolves to the model's name when that names a modality."""
+        if modality in (None, "auto"):
+            name = getattr(self.config, "name", "ar+nar")
+            return name if name in ("ar+nar", "nar-len") else "ar+nar"
+        return modality
+
+    @torch.inference_mode()
+    def batched_inference(self, texts, references=None, languages=None, text_languages=None, out_paths=None,
+                          len_list=None, rank=0, world_size=1, **sampling_kwargs):
+        """-> list of (R_i, 8) code tensors for THIS rank's utterances plus their indices when
+        world_size > 1 (use ``gather_codes`` to assemble), else the full list in input order."""
+        batch_size = sampling_kwargs.pop("batch_size", self.batch_size)
+        modality = self.modality(sampling_kwargs.pop("modality", "auto"))
+        for k in ("input_prompt_length", "seed", "tqdm", "use_lora", "dtype", "amp"):
+            sampling_kwargs.pop(k, None)
+        n = len(texts)
+        references = list(references) if references else [None] * n
+        languages = list(languages) if languages else [torch.tensor([0], dtype=torch.uint8)] * n
+        lengths = [sort_key(t, r) for t, r in zip(texts, references)]
+        mine = shard_utterances(lengths, world_size)[rank]
+        results = {}
+        for idx in chunk(mine, batch_size):
+            kw = dict(task_list=["tts"] * len(idx), phns_list=[texts[i] for i in idx],
+                      proms_list=[references[i] for i in idx], lang_list=[languages[i] for i in idx])
+            if modality == "nar-len":
+                if len_list is None:
+                    raise NotImplementedError("the `len` task (duration prediction) is not built: pass len_list")
+                resps = self.model(**kw, len_list=[len_list[i] for i in idx], **sampling_kwargs)
+            else:
+                resps = self.model(**kw, **sampling_kwargs)
+                resps = self.model(**kw, resps_list=resps, **sampling_kwargs)
+            for i, r in zip(idx, resps):
+                results[i] = r
+        if world_size == 1:
+            return [results[i] for i in range(n)]
+        return [results[i] for i in mine], mine
