@@ -1,8 +1,25 @@
-// Dev micro-benchmark (not part of the library): time the decode linears and a pure streaming
-// read over a weight set larger than the Infinity Cache, so every launch reads HBM-cold data.
+// Dev micro-benchmark (not part of the library): the AR decode layer chain
+// (QKV -> decode attention -> o_proj -> gate/up -> down) on weights / KV caches larger than the
+// Infinity Cache, eager and as a hipGraph, plus each kernel alone in a dependent chain and the
+// pure-streaming floor for the same byte counts.  Per-kernel durations: run under
+//   rocprofv3 --kernel-trace --stats -- ./tools/micro_dec
 #include "../vall-e_amd/csrc/common.h"
 #include <vector>
 #include <stdio.h>
+#include <stdlib.h>
+
+template <int BYTES_PER_BLOCK, int NT>
+__global__ __launch_bounds__(NT) void stream2_kernel(const uint4* __restrict__ p, uint4* out, size_t block_stride16) {
+    const uint4* base = p + (size_t)blockIdx.x * block_stride16;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    constexpr int N = BYTES_PER_BLOCK / 16 / NT;
+    uint4 v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = base[threadIdx.x + NT * i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { acc.x ^= v[i].x; acc.y ^= v[i].y; acc.z ^= v[i].z; acc.w ^= v[i].w; }
+    if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) out[blockIdx.x] = acc;
+}
 
 template <int BYTES_PER_BLOCK>
 __global__ __launch_bounds__(256) void stream_kernel(const uint4* __restrict__ p, uint4* out) {
@@ -18,60 +35,114 @@ __global__ __launch_bounds__(256) void stream_kernel(const uint4* __restrict__ p
 }
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+#define RC(x) do { int rc_ = (x); if (rc_ != 0) { printf("valle error %d: %s (line %d)\n", rc_, valle_last_error(), __LINE__); return 1; } } while (0)
 
-int main() {
-    const int d = 1024, f = 4096, B = 16, L = 24;   // 24 "layers" of weights = 805 MB > 256 MiB MALL
-    std::vector<bf16*> wqkv(L), wo(L), wgu(L), wdn(L);
+int main(int argc, char** argv) {
+    const int d = 1024, f = 4096, H = 16, L = 24;   // 24 layers of weights = 805 MB > 256 MiB MALL
+    const int B = argc > 1 ? atoi(argv[1]) : 16;
+    const int ctx = argc > 2 ? atoi(argv[2]) : 536;
+    const int CT = 768;
+    const int dbg = argc > 3 ? atoi(argv[3]) : 0;
+    std::vector<bf16*> wqkv(L), wo(L), wgu(L), wdn(L), kc(L), vc(L);
+    const size_t per = (size_t)B * H * CT * 64;
     for (int l = 0; l < L; ++l) {
         CK(hipMalloc(&wqkv[l], (size_t)3 * d * d * 2)); CK(hipMemset(wqkv[l], 0x11, (size_t)3 * d * d * 2));
         CK(hipMalloc(&wo[l], (size_t)d * d * 2));       CK(hipMemset(wo[l], 0x11, (size_t)d * d * 2));
         CK(hipMalloc(&wgu[l], (size_t)2 * f * d * 2));  CK(hipMemset(wgu[l], 0x11, (size_t)2 * f * d * 2));
         CK(hipMalloc(&wdn[l], (size_t)d * f * 2));      CK(hipMemset(wdn[l], 0x11, (size_t)d * f * 2));
+        CK(hipMalloc(&kc[l], per * 2)); CK(hipMemset(kc[l], 0x3c, per * 2));
+        CK(hipMalloc(&vc[l], per * 2)); CK(hipMemset(vc[l], 0x3c, per * 2));
     }
-    bf16 *x, *h, *ff, *nw; uint4* sink;
-    CK(hipMalloc(&x, B * d * 2)); CK(hipMalloc(&h, B * d * 2)); CK(hipMalloc(&ff, B * f * 2)); CK(hipMalloc(&nw, d * 2));
+    bf16 *x, *att, *ff, *nw, *qkv; uint4* sink; float* rope; int32_t *pos, *ctxl;
+    CK(hipMalloc(&x, B * d * 2)); CK(hipMalloc(&att, B * d * 2)); CK(hipMalloc(&ff, B * f * 2)); CK(hipMalloc(&nw, d * 2));
+    CK(hipMalloc(&qkv, B * 3 * d * 2)); CK(hipMalloc(&rope, 1024 * 64 * 4)); CK(hipMalloc(&pos, B * 4)); CK(hipMalloc(&ctxl, B * 4));
     CK(hipMalloc(&sink, 1 << 20));
-    CK(hipMemset(x, 0x3c, B * d * 2)); CK(hipMemset(ff, 0x3c, B * f * 2)); CK(hipMemset(nw, 0x3c, d * 2));
+    float* ssq; CK(hipMalloc(&ssq, 16 * 256 * 4)); CK(hipMemset(ssq, 0, 16 * 256 * 4));
+    CK(hipMemset(x, 0x3c, B * d * 2)); CK(hipMemset(att, 0x3c, B * d * 2)); CK(hipMemset(ff, 0x3c, B * f * 2)); CK(hipMemset(nw, 0x3c, d * 2));
+    CK(hipMemset(qkv, 0x3c, B * 3 * d * 2)); CK(hipMemset(rope, 0, 1024 * 64 * 4)); CK(hipMemset(pos, 0, B * 4));
+    { std::vector<int32_t> hc(B, ctx); CK(hipMemcpy(ctxl, hc.data(), B * 4, hipMemcpyHostToDevice)); }
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = 20;
-    auto timeit = [&](const char* name, double mb, auto fn) {
-        for (int l = 0; l < L; ++l) fn(l);
-        hipStreamSynchronize(s);
-        hipEventRecord(e0, s);
-        for (int r = 0; r < reps; ++r) for (int l = 0; l < L; ++l) fn(l);
-        hipEventRecord(e1, s);
-        hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        const double us = ms * 1e3 / (reps * L);
-        printf("%-34s %7.2f us/launch  %6.2f TB/s\n", name, us, mb / us);
-    };
-    timeit("stream 16.8MB (512 blk x 32KB)", 16.78, [&](int l) { stream_kernel<32768><<<512, 256, 0, s>>>((const uint4*)wgu[l], sink); });
-    timeit("stream 16.8MB (1024 blk x 16KB)", 16.78, [&](int l) { stream_kernel<16384><<<1024, 256, 0, s>>>((const uint4*)wgu[l], sink); });
-    timeit("stream 16.8MB (256 blk x 64KB)", 16.78, [&](int l) { stream_kernel<65536><<<256, 256, 0, s>>>((const uint4*)wgu[l], sink); });
-    timeit("stream 8.4MB (256 blk x 32KB)", 8.39, [&](int l) { stream_kernel<32768><<<256, 256, 0, s>>>((const uint4*)wdn[l], sink); });
-    timeit("stream 6.3MB (192 blk x 32KB)", 6.29, [&](int l) { stream_kernel<32768><<<192, 256, 0, s>>>((const uint4*)wqkv[l], sink); });
-    timeit("stream 2MB (64 blk x 32KB)", 2.10, [&](int l) { stream_kernel<32768><<<64, 256, 0, s>>>((const uint4*)wo[l], sink); });
-    timeit("stream 8.4MB (64 blk x 128KB)", 8.39, [&](int l) { stream_kernel<131072><<<64, 256, 0, s>>>((const uint4*)wdn[l], sink); });
-    timeit("stream 2MB (256 blk x 8KB)", 2.10, [&](int l) { stream_kernel<8192><<<256, 256, 0, s>>>((const uint4*)wo[l], sink); });
+
     auto mk = [&](const bf16* xx, const bf16* norm, const bf16* W, const bf16* resid, void* out, int ldo, int N, int K) {
-        DecArgs a{}; a.x = xx; a.norm_w = norm; a.eps = 1e-6f; a.W = W; a.resid = resid; a.out = out; a.ldo = ldo; a.B = B; a.N = N; a.K = K; return a; };
-    timeit("dec gate/up GEGLU (16.8MB)", 16.78, [&](int l) { valle_dec_linear_bf16(mk(x, nw, wgu[l], nullptr, ff, f, 2 * f, d), VALLE_EPI_GEGLU, s); });
-    timeit("dec down RESID (8.4MB)", 8.39, [&](int l) { valle_dec_linear_bf16(mk(ff, nullptr, wdn[l], x, x, d, d, f), VALLE_EPI_RESID, s); });
-    timeit("dec o_proj RESID (2MB)", 2.10, [&](int l) { valle_dec_linear_bf16(mk(h, nullptr, wo[l], x, x, d, d, d), VALLE_EPI_RESID, s); });
-    {   // decode attention over a KV cache set larger than the Infinity Cache
-        const int H = 16, CT = 768, NL = 6;
-        const size_t per = (size_t)B * H * CT * 64;
-        bf16 *kc, *vc, *qkvb, *att; int32_t* ctx;
-        CK(hipMalloc(&kc, per * NL * 2)); CK(hipMalloc(&vc, per * NL * 2)); CK(hipMemset(kc, 0x3c, per * NL * 2)); CK(hipMemset(vc, 0x3c, per * NL * 2));
-        CK(hipMalloc(&qkvb, B * 3 * d * 2)); CK(hipMemset(qkvb, 0x3c, B * 3 * d * 2)); CK(hipMalloc(&att, B * d * 2));
-        CK(hipMalloc(&ctx, B * 4));
-        for (int cl : {311, 536, 760}) {
-            std::vector<int32_t> hc(B, cl); CK(hipMemcpy(ctx, hc.data(), B * 4, hipMemcpyHostToDevice));
-            char nm[64]; snprintf(nm, sizeof nm, "attn decode ctx=%d", cl);
-            timeit(nm, (double)B * H * cl * 256 / 1e6, [&](int l) { valle_attn_decode_launch(qkvb, kc + per * (l % NL), vc + per * (l % NL), ctx, nullptr, att, B, H, 64, CT, 0, VALLE_BF16, s); });
+        DecArgs a{}; a.x = xx; a.norm_w = norm; a.eps = 1e-6f; a.W = W; a.resid = resid; a.out = out; a.ldo = ldo; a.B = B; a.N = N; a.K = K; a.dbg = dbg; return a; };
+    auto k_qkv = [&](int l) { DecArgs a = mk(x, nw, wqkv[l], nullptr, qkv, 3 * d, 3 * d, d);
+        a.rope = rope; a.pos = pos; a.ctx_len = ctxl; a.slot = nullptr; a.kc = kc[l]; a.vc = vc[l]; a.cache_T = CT; a.H = H; a.d = d;
+        return valle_dec_linear_bf16(a, DEC_EPI_QKV, s); };
+    auto k_attn = [&](int l) { return valle_attn_decode_launch(qkv, kc[l], vc[l], ctxl, nullptr, att, B, H, 64, CT, 1, VALLE_BF16, s); };
+    auto k_o = [&](int l) { return valle_dec_linear_bf16(mk(att, nullptr, wo[l], x, x, d, d, d), VALLE_EPI_RESID, s); };
+    auto k_gu = [&](int l) { return valle_dec_linear_bf16(mk(x, nw, wgu[l], nullptr, ff, f, 2 * f, d), VALLE_EPI_GEGLU, s); };
+    auto k_dn = [&](int l) { return valle_dec_linear_bf16(mk(ff, nullptr, wdn[l], x, x, d, d, f), VALLE_EPI_RESID, s); };
+    auto mkw = [&](const bf16* xx, int norm, const bf16* W, const bf16* resid, void* out, int ldo, int N, int K) {
+        DecWArgs a{}; a.x = xx; a.norm = norm | (dbg << 4); a.eps = 1e-6f; a.W = W; a.resid = resid; a.out = out; a.ldo = ldo; a.B = B; a.N = N; a.K = K; a.ssq_in = ssq; a.ssq_out = resid ? ssq : nullptr; return a; };
+    auto w_qkv = [&](int l) { DecWArgs a = mkw(x, 1, wqkv[l], nullptr, qkv, 3 * d, 3 * d, d);
+        a.rope = rope; a.pos = pos; a.ctx_len = ctxl; a.slot = nullptr; a.kc = kc[l]; a.vc = vc[l]; a.cache_T = CT; a.H = H; a.d = d;
+        return valle_dec_wave_linear(a, DEC_EPI_QKV, s); };
+    auto w_o = [&](int l) { return valle_dec_wave_linear(mkw(att, 0, wo[l], x, x, d, d, d), VALLE_EPI_RESID, s); };
+    auto w_gu = [&](int l) { return valle_dec_wave_linear(mkw(x, 1, wgu[l], nullptr, ff, f, 2 * f, d), VALLE_EPI_GEGLU, s); };
+    auto w_dn = [&](int l) { return valle_dec_wave_linear(mkw(ff, 0, wdn[l], x, x, d, d, f), VALLE_EPI_RESID, s); };
+    auto w_attn = [&](int l) { return valle_attn_decode_bf16(qkv, 3 * d, kc[l], vc[l], ctxl, nullptr, att, B, H, CT, 1, 1 | (dbg & 48), s); };
+    auto wlayer = [&](int l) { int rc = w_qkv(l); rc |= w_attn(l); rc |= w_o(l); rc |= w_gu(l); rc |= w_dn(l); return rc; };
+    auto layer = [&](int l) { int rc = k_qkv(l); rc |= k_attn(l); rc |= k_o(l); rc |= k_gu(l); rc |= k_dn(l); return rc; };
+
+    // times `fn(l)` for l in 0..L-1 as one dependent chain; graph = captured once, replayed
+    auto timeit = [&](const char* name, double mb, bool graph, auto fn) -> int {
+        float ms;
+        for (int l = 0; l < L; ++l) RC(fn(l));
+        CK(hipStreamSynchronize(s));
+        if (!graph) {
+            CK(hipEventRecord(e0, s));
+            for (int r = 0; r < reps; ++r) for (int l = 0; l < L; ++l) fn(l);
+            CK(hipEventRecord(e1, s));
+            CK(hipEventSynchronize(e1));
+        } else {
+            hipGraph_t g; hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            for (int l = 0; l < L; ++l) fn(l);
+            CK(hipStreamEndCapture(s, &g));
+            CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+            CK(hipEventRecord(e0, s));
+            for (int r = 0; r < reps; ++r) CK(hipGraphLaunch(ge, s));
+            CK(hipEventRecord(e1, s));
+            CK(hipEventSynchronize(e1));
+            CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
         }
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / (reps * L);
+        printf("%-40s %-6s %7.2f us  %6.2f TB/s\n", name, graph ? "graph" : "eager", us, mb / us);
+        return 0;
+    };
+    const double mb_qkv = 6.29, mb_o = 2.10, mb_gu = 16.78, mb_dn = 8.39, mb_att = (double)B * H * (ctx + 1) * 256 / 1e6;
+    printf("B=%d ctx=%d\n", B, ctx);
+    if (timeit("stream 16.8MB (256 blk x 64KB)", 16.78, true, [&](int l) { stream_kernel<65536><<<256, 256, 0, s>>>((const uint4*)wgu[l], sink); return 0; })) return 1;
+    if (timeit("stream 8.4MB (256 blk x 32KB)", 8.39, true, [&](int l) { stream_kernel<32768><<<256, 256, 0, s>>>((const uint4*)wdn[l], sink); return 0; })) return 1;
+    if (timeit("stream 6.3MB (192 blk x 32KB)", 6.29, true, [&](int l) { stream_kernel<32768><<<192, 256, 0, s>>>((const uint4*)wqkv[l], sink); return 0; })) return 1;
+    if (timeit("stream 2MB (64 blk x 32KB)", 2.10, true, [&](int l) { stream_kernel<32768><<<64, 256, 0, s>>>((const uint4*)wo[l], sink); return 0; })) return 1;
+    // KV-shaped streams over ONE layer's K cache (B*H regions of CT*128 B; the buffer holds exactly B*H*CT*128 B)
+    if (B == 16) {
+        if (timeit("stream 25MB (256 blk x 96KB, 512thr)", 25.2, true, [&](int l) { stream2_kernel<98304, 512><<<256, 512, 0, s>>>((const uint4*)kc[l], sink, (size_t)98304 / 16); return 0; })) return 1;
+        if (timeit("stream 25MB (256 blk x 96KB, 256thr)", 25.2, true, [&](int l) { stream2_kernel<98304, 256><<<256, 256, 0, s>>>((const uint4*)kc[l], sink, (size_t)98304 / 16); return 0; })) return 1;
+        if (timeit("stream 25MB (512 blk x 48KB, 256thr)", 25.2, true, [&](int l) { stream2_kernel<49152, 256><<<512, 256, 0, s>>>((const uint4*)kc[l], sink, (size_t)49152 / 16); return 0; })) return 1;
+        if (timeit("stream 25MB (1024 blk x 24KB, 256thr)", 25.2, true, [&](int l) { stream2_kernel<24576, 256><<<1024, 256, 0, s>>>((const uint4*)kc[l], sink, (size_t)24576 / 16); return 0; })) return 1;
     }
+    if (timeit("dec qkv+rope+append", mb_qkv, true, k_qkv)) return 1;
+    if (timeit("dec attention", mb_att, true, k_attn)) return 1;
+    if (timeit("dec o_proj", mb_o, true, k_o)) return 1;
+    if (timeit("dec gate/up GEGLU", mb_gu, true, k_gu)) return 1;
+    if (timeit("dec down", mb_dn, true, k_dn)) return 1;
+    if (B <= 16) {
+        if (timeit("wave qkv+rope+append", mb_qkv, true, w_qkv)) return 1;
+        if (timeit("wave attention", mb_att, true, w_attn)) return 1;
+        if (timeit("wave o_proj", mb_o, true, w_o)) return 1;
+        if (timeit("wave gate/up GEGLU", mb_gu, true, w_gu)) return 1;
+        if (timeit("wave down", mb_dn, true, w_dn)) return 1;
+    }
+    const double mb_layer = mb_qkv + mb_o + mb_gu + mb_dn + mb_att;
+    if (timeit("LAYER (5 kernels)", mb_layer, false, layer)) return 1;
+    if (timeit("LAYER (5 kernels)", mb_layer, true, layer)) return 1;
+    if (B <= 16 && timeit("WAVE LAYER (5 kernels)", mb_layer, true, wlayer)) return 1;
     printf("last error: %s\n", valle_last_error());
     return 0;
 }

@@ -76,6 +76,7 @@ struct valle_model {
     const void** head_w;
     const float** head_b;
     const void** head_p;
+    const void** head_pn;
     int32_t* head_n;
 };
 
@@ -106,6 +107,23 @@ struct DecArgs {
     int dbg;   // dev ablation switches (0 in production)
 };
 int valle_dec_linear_bf16(const DecArgs& a, int epilogue, hipStream_t s);
+
+// wave-streaming decode linears (dec_linear.hip): activations in fragment order, norm weight folded into W
+struct DecWArgs {
+    const bf16* x; const bf16* W; const float* bias; const bf16* resid;
+    void* out; int ldo;
+    int B, N, K;
+    float eps; int norm;
+    const float* ssq_in;        // norm: [16][K/16] per-tile sums of squares of x's rows
+    float* ssq_out;             // RESID: [16][N/16] the same for the rows this kernel writes (may be NULL)
+    const float* rope; const int32_t* pos; const int32_t* ctx_len; const int32_t* slot;
+    bf16* kc; bf16* vc; int cache_T; int H; int d;
+};
+int valle_dec_wave_linear(const DecWArgs& a, int epilogue, hipStream_t s);
+
+int valle_attn_decode_bf16(const void* q, size_t q_row_stride, const void* kcache, const void* vcache,
+                           const int32_t* ctx_len, const int32_t* cache_slot, void* out, int B, int H, int cache_T,
+                           int ctx_extra, int out_frag, hipStream_t s);
 
 // attention launchers (ops_basic.hip)
 extern "C" int valle_attn_prefill_rowwise(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int M,

@@ -13,7 +13,8 @@ extern "C" int valle_attn_prefill(const void* qkv, void* out, const int32_t* cu_
 extern "C" int valle_model_create(const valle_config* cfg, const void* emb, const float* rope,
                                   const valle_layer_weights* layers_host, const void* final_norm,
                                   int n_cls, const void* const* head_w_host, const float* const* head_b_host,
-                                  const int32_t* head_n_host, const void* const* head_p_host, valle_model** out) {
+                                  const int32_t* head_n_host, const void* const* head_p_host,
+                                  const void* const* head_pn_host, valle_model** out) {
     VALLE_REQUIRE(cfg && emb && rope && layers_host && final_norm && out, VALLE_E_ARG, "valle_model_create: null pointer");
     VALLE_REQUIRE(cfg->n_heads > 0 && cfg->d_model % cfg->n_heads == 0 && cfg->d_model / cfg->n_heads == 64,
                   VALLE_E_UNSUPPORTED, "valle_model_create: head_dim must be 64 (d_model %d, heads %d)", cfg->d_model, cfg->n_heads);
@@ -29,11 +30,13 @@ extern "C" int valle_model_create(const valle_config* cfg, const void* emb, cons
     m->head_b = (const float**)malloc(sizeof(float*) * (n_cls > 0 ? n_cls : 1));
     m->head_n = (int32_t*)malloc(sizeof(int32_t) * (n_cls > 0 ? n_cls : 1));
     m->head_p = (const void**)malloc(sizeof(void*) * (n_cls > 0 ? n_cls : 1));
+    m->head_pn = (const void**)malloc(sizeof(void*) * (n_cls > 0 ? n_cls : 1));
     for (int k = 0; k < n_cls; ++k) {
         m->head_w[k] = head_w_host[k];
         m->head_b[k] = head_b_host ? head_b_host[k] : nullptr;
         m->head_n[k] = head_n_host[k];
         m->head_p[k] = head_p_host ? head_p_host[k] : nullptr;
+        m->head_pn[k] = head_pn_host ? head_pn_host[k] : nullptr;
     }
     *out = m;
     return VALLE_OK;
@@ -41,7 +44,7 @@ extern "C" int valle_model_create(const valle_config* cfg, const void* emb, cons
 
 extern "C" void valle_model_destroy(valle_model* m) {
     if (!m) return;
-    free(m->layers); free((void*)m->head_w); free((void*)m->head_b); free(m->head_n); free((void*)m->head_p); free(m);
+    free(m->layers); free((void*)m->head_w); free((void*)m->head_b); free(m->head_n); free((void*)m->head_p); free((void*)m->head_pn); free(m);
 }
 
 // ------------------------------------------------------------------ small helpers
@@ -76,6 +79,29 @@ __global__ __launch_bounds__(128) void dec_prepare_kernel(const T* __restrict__ 
     const T* src = emb + (size_t)(emb_row0 + tok) * d;
     for (int c = threadIdx.x * VEC; c < d; c += 128 * VEC)
         *reinterpret_cast<vec_t*>(x + (size_t)b * d + c) = *reinterpret_cast<const vec_t*>(src + c);
+}
+
+// wave-streaming decode path (dec_linear.hip): x in fragment order + per-tile sums of squares
+__global__ __launch_bounds__(128) void dec_prepare_frag_kernel(const bf16* __restrict__ emb, int emb_row0,
+                                                               const int32_t* __restrict__ seq, int seq_cap,
+                                                               const int32_t* __restrict__ seq_len,
+                                                               const int32_t* __restrict__ resp_pos0,
+                                                               bf16* __restrict__ xf, float* __restrict__ ssq,
+                                                               int32_t* __restrict__ pos, int d) {
+    const int b = blockIdx.x;
+    const int n = seq_len[b];
+    const int tok = seq[(size_t)b * seq_cap + (n - 1)];
+    if (threadIdx.x == 0) pos[b] = (resp_pos0 ? resp_pos0[b] : 0) + n - 1;
+    const bf16* src = emb + (size_t)(emb_row0 + tok) * d;
+    for (int c = threadIdx.x * 8; c < d; c += 128 * 8) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c);
+        float q2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q2 = fmaf((float)v[e], (float)v[e], q2);
+        q2 += __shfl_xor(q2, 1, 64);                                   // the two 8-column halves of a 16-column tile
+        *reinterpret_cast<bf16x8*>(xf + ((((c >> 5) << 6) + (((c >> 3) & 3) << 4) + b) << 3)) = v;
+        if ((threadIdx.x & 1) == 0) ssq[(size_t)b * (d >> 4) + (c >> 4)] = q2;
+    }
 }
 
 struct Carver {
@@ -159,6 +185,8 @@ extern "C" size_t valle_decode_workspace_bytes(const valle_model* m, int B) {
     t += align_up((size_t)B * f * es, 256);            // ff
     t += align_up((size_t)B * 2048 * sizeof(float), 256);  // logits
     t += align_up((size_t)(B + 1) * sizeof(int32_t), 256) * 2 + align_up((size_t)B * sizeof(int32_t), 256);
+    t += align_up((size_t)16 * (d / 16) * sizeof(float), 256);   // per-tile sums of squares (wave-streaming path)
+    t += align_up((size_t)16 * d * es, 256) * 2 + align_up((size_t)16 * f * es, 256);  // its 16-row fragment-order x, att, ff
     return t;
 }
 
@@ -184,16 +212,25 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
     float* lg_ws = (float*)ws.take((size_t)B * 2048 * sizeof(float));
     int32_t* pos = (int32_t*)ws.take((size_t)(B + 1) * sizeof(int32_t));
     int32_t* cu = (int32_t*)ws.take((size_t)(B + 1) * sizeof(int32_t));
+    float* ssq = (float*)ws.take((size_t)16 * (d / 16) * sizeof(float));
+    // the wave-streaming path keeps its activations as 16-row fragment-order matrices whatever B is
+    bf16* xf = (bf16*)ws.take((size_t)16 * d * es);
+    bf16* attf = (bf16*)ws.take((size_t)16 * d * es);
+    bf16* fff = (bf16*)ws.take((size_t)16 * f * es);
     VALLE_REQUIRE(ws.ok, VALLE_E_WORKSPACE, "valle_ar_decode: workspace %zu B too small (need %zu)", workspace_bytes,
                   valle_decode_workspace_bytes(m, B));
     hipStream_t s = (hipStream_t)stream;
-    const bool fused = (dt == VALLE_BF16) && B <= 32 && (d == 256 || d == 1024) && (f == 256 || f == 1024 || f == 4096) &&
+    const bool wavepath = (dt == VALLE_BF16) && B <= 16 && (d == 256 || d == 1024) && (f == 1024 || f == 4096) &&
+                          m->layers[0].pn_qkv && m->layers[0].p_o && m->layers[0].pn_gu && m->layers[0].p_down && m->head_pn[st->head];
+    const bool fused = !wavepath && (dt == VALLE_BF16) && B <= 32 && (d == 256 || d == 1024) && (f == 256 || f == 1024 || f == 4096) &&
                        m->layers[0].p_qkv && m->layers[0].p_o && m->layers[0].p_gu && m->layers[0].p_down && m->head_p[st->head];
     int rc;
     for (int step = 0; step < n_steps; ++step) {
         float* lg = logits_out ? logits_out + (size_t)step * B * ld_logits : lg_ws;
         const int ldl = logits_out ? ld_logits : 2048;
-        if (dt == VALLE_BF16)
+        if (wavepath)
+            dec_prepare_frag_kernel<<<B, 128, 0, s>>>((const bf16*)m->emb, st->resp_emb_row0, st->seq, st->max_steps, st->seq_len, st->resp_pos0, xf, ssq, pos, d);
+        else if (dt == VALLE_BF16)
             dec_prepare_kernel<bf16><<<B, 128, 0, s>>>((const bf16*)m->emb, st->resp_emb_row0, st->seq, st->max_steps, st->seq_len, st->resp_pos0, (bf16*)x, pos, cu, d, B);
         else
             dec_prepare_kernel<float><<<B, 128, 0, s>>>((const float*)m->emb, st->resp_emb_row0, st->seq, st->max_steps, st->seq_len, st->resp_pos0, (float*)x, pos, cu, d, B);
@@ -202,7 +239,25 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
             const valle_layer_weights& w = m->layers[l];
             void* kc = (char*)st->kcache + (size_t)l * st->cache_layer_stride * es;
             void* vc = (char*)st->vcache + (size_t)l * st->cache_layer_stride * es;
-            if (fused) {
+            if (wavepath) {
+                DecWArgs a{};
+                a.x = xf; a.W = (const bf16*)w.pn_qkv; a.out = qkv; a.ldo = 3 * d; a.B = B; a.N = 3 * d; a.K = d;
+                a.eps = c.rms_eps; a.norm = 1; a.ssq_in = ssq;
+                a.rope = m->rope; a.pos = pos; a.ctx_len = st->ctx_len; a.slot = st->cache_slot;
+                a.kc = (bf16*)kc; a.vc = (bf16*)vc; a.cache_T = st->cache_T; a.H = H; a.d = d;
+                RUN(valle_dec_wave_linear(a, DEC_EPI_QKV, s));
+                RUN(valle_attn_decode_bf16(qkv, (size_t)3 * d, kc, vc, st->ctx_len, st->cache_slot, attf, B, H, st->cache_T, 1, 1, s));
+                DecWArgs o{};
+                o.x = attf; o.W = (const bf16*)w.p_o; o.resid = xf; o.out = xf; o.B = B; o.N = d; o.K = d; o.ssq_out = ssq;
+                RUN(valle_dec_wave_linear(o, VALLE_EPI_RESID, s));
+                DecWArgs g{};
+                g.x = xf; g.W = (const bf16*)w.pn_gu; g.out = fff; g.B = B; g.N = 2 * f; g.K = d;
+                g.eps = c.rms_eps; g.norm = 1; g.ssq_in = ssq;
+                RUN(valle_dec_wave_linear(g, VALLE_EPI_GEGLU, s));
+                DecWArgs dn{};
+                dn.x = fff; dn.W = (const bf16*)w.p_down; dn.resid = xf; dn.out = xf; dn.B = B; dn.N = d; dn.K = f; dn.ssq_out = ssq;
+                RUN(valle_dec_wave_linear(dn, VALLE_EPI_RESID, s));
+            } else if (fused) {
                 DecArgs a{};
                 a.x = (const bf16*)x; a.norm_w = (const bf16*)w.ln1; a.eps = c.rms_eps; a.W = (const bf16*)w.p_qkv;
                 a.out = qkv; a.ldo = 3 * d; a.B = B; a.N = 3 * d; a.K = d;
@@ -231,7 +286,12 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
                 RUN(valle_gemm(ff, w.w_down, nullptr, x, x, B, d, f, d, VALLE_EPI_RESID, dt, s));
             }
         }
-        if (fused) {
+        if (wavepath) {
+            DecWArgs hd{};
+            hd.x = xf; hd.W = (const bf16*)m->head_pn[st->head]; hd.bias = m->head_b[st->head]; hd.out = lg; hd.ldo = ldl;
+            hd.B = B; hd.N = st->vocab; hd.K = d; hd.eps = c.rms_eps; hd.norm = 1; hd.ssq_in = ssq;
+            RUN(valle_dec_wave_linear(hd, VALLE_EPI_F32OUT, s));
+        } else if (fused) {
             DecArgs hd{};
             hd.x = (const bf16*)x; hd.norm_w = (const bf16*)m->final_norm; hd.eps = c.rms_eps; hd.W = (const bf16*)m->head_p[st->head];
             hd.bias = m->head_b[st->head]; hd.out = lg; hd.ldo = ldl; hd.B = B; hd.N = st->vocab; hd.K = d;
