@@ -34,6 +34,15 @@ __global__ __launch_bounds__(256) void stream_kernel(const uint4* __restrict__ p
     if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) out[blockIdx.x] = acc;
 }
 
+// pseudo-random bf16 in (-2, 2) with random mantissas: realistic bit toggling (memset patterns run faster)
+__global__ void fill_rand(uint16_t* p, size_t n, uint32_t seed) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        p[i] = (uint16_t)(((h & 1u) << 15) | ((118u + ((h >> 1) & 7u)) << 7) | ((h >> 8) & 0x7fu));
+    }
+}
+#define FILL(ptr, bytes, seed) fill_rand<<<1024, 256>>>((uint16_t*)(ptr), (size_t)(bytes) / 2, (seed))
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 #define RC(x) do { int rc_ = (x); if (rc_ != 0) { printf("valle error %d: %s (line %d)\n", rc_, valle_last_error(), __LINE__); return 1; } } while (0)
 
@@ -46,20 +55,20 @@ int main(int argc, char** argv) {
     std::vector<bf16*> wqkv(L), wo(L), wgu(L), wdn(L), kc(L), vc(L);
     const size_t per = (size_t)B * H * CT * 64;
     for (int l = 0; l < L; ++l) {
-        CK(hipMalloc(&wqkv[l], (size_t)3 * d * d * 2)); CK(hipMemset(wqkv[l], 0x11, (size_t)3 * d * d * 2));
-        CK(hipMalloc(&wo[l], (size_t)d * d * 2));       CK(hipMemset(wo[l], 0x11, (size_t)d * d * 2));
-        CK(hipMalloc(&wgu[l], (size_t)2 * f * d * 2));  CK(hipMemset(wgu[l], 0x11, (size_t)2 * f * d * 2));
-        CK(hipMalloc(&wdn[l], (size_t)d * f * 2));      CK(hipMemset(wdn[l], 0x11, (size_t)d * f * 2));
-        CK(hipMalloc(&kc[l], per * 2)); CK(hipMemset(kc[l], 0x3c, per * 2));
-        CK(hipMalloc(&vc[l], per * 2)); CK(hipMemset(vc[l], 0x3c, per * 2));
+        CK(hipMalloc(&wqkv[l], (size_t)3 * d * d * 2)); FILL(wqkv[l], (size_t)3 * d * d * 2, 11 + l);
+        CK(hipMalloc(&wo[l], (size_t)d * d * 2));       FILL(wo[l], (size_t)d * d * 2, 111 + l);
+        CK(hipMalloc(&wgu[l], (size_t)2 * f * d * 2));  FILL(wgu[l], (size_t)2 * f * d * 2, 211 + l);
+        CK(hipMalloc(&wdn[l], (size_t)d * f * 2));      FILL(wdn[l], (size_t)d * f * 2, 311 + l);
+        CK(hipMalloc(&kc[l], per * 2)); FILL(kc[l], per * 2, 411 + l);
+        CK(hipMalloc(&vc[l], per * 2)); FILL(vc[l], per * 2, 511 + l);
     }
     bf16 *x, *att, *ff, *nw, *qkv; uint4* sink; float* rope; int32_t *pos, *ctxl;
-    CK(hipMalloc(&x, B * d * 2)); CK(hipMalloc(&att, B * d * 2)); CK(hipMalloc(&ff, B * f * 2)); CK(hipMalloc(&nw, d * 2));
+    CK(hipMalloc(&x, 32 * d * 2)); CK(hipMalloc(&att, 32 * d * 2)); CK(hipMalloc(&ff, 32 * f * 2)); CK(hipMalloc(&nw, d * 2));
     CK(hipMalloc(&qkv, B * 3 * d * 2)); CK(hipMalloc(&rope, 1024 * 64 * 4)); CK(hipMalloc(&pos, B * 4)); CK(hipMalloc(&ctxl, B * 4));
     CK(hipMalloc(&sink, 1 << 20));
     float* ssq; CK(hipMalloc(&ssq, 16 * 256 * 4)); CK(hipMemset(ssq, 0, 16 * 256 * 4));
-    CK(hipMemset(x, 0x3c, B * d * 2)); CK(hipMemset(att, 0x3c, B * d * 2)); CK(hipMemset(ff, 0x3c, B * f * 2)); CK(hipMemset(nw, 0x3c, d * 2));
-    CK(hipMemset(qkv, 0x3c, B * 3 * d * 2)); CK(hipMemset(rope, 0, 1024 * 64 * 4)); CK(hipMemset(pos, 0, B * 4));
+    FILL(x, 16 * d * 2, 1); FILL(att, 16 * d * 2, 2); FILL(ff, 16 * f * 2, 3); FILL(nw, d * 2, 4);
+    FILL(qkv, B * 3 * d * 2, 5); CK(hipDeviceSynchronize()); CK(hipMemset(rope, 0, 1024 * 64 * 4)); CK(hipMemset(pos, 0, B * 4));
     { std::vector<int32_t> hc(B, ctx); CK(hipMemcpy(ctxl, hc.data(), B * 4, hipMemcpyHostToDevice)); }
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -75,7 +84,7 @@ int main(int argc, char** argv) {
     auto k_gu = [&](int l) { return valle_dec_linear_bf16(mk(x, nw, wgu[l], nullptr, ff, f, 2 * f, d), VALLE_EPI_GEGLU, s); };
     auto k_dn = [&](int l) { return valle_dec_linear_bf16(mk(ff, nullptr, wdn[l], x, x, d, d, f), VALLE_EPI_RESID, s); };
     auto mkw = [&](const bf16* xx, int norm, const bf16* W, const bf16* resid, void* out, int ldo, int N, int K) {
-        DecWArgs a{}; a.x = xx; a.norm = norm | (dbg << 4); a.eps = 1e-6f; a.W = W; a.resid = resid; a.out = out; a.ldo = ldo; a.B = B; a.N = N; a.K = K; a.ssq_in = ssq; a.ssq_out = resid ? ssq : nullptr; return a; };
+        DecWArgs a{}; a.x = xx; a.norm = norm; a.eps = 1e-6f; a.W = W; a.resid = resid; a.out = out; a.ldo = ldo; a.B = B; a.N = N; a.K = K; a.ssq_in = ssq; a.ssq_out = resid ? ssq : nullptr; return a; };
     auto w_qkv = [&](int l) { DecWArgs a = mkw(x, 1, wqkv[l], nullptr, qkv, 3 * d, 3 * d, d);
         a.rope = rope; a.pos = pos; a.ctx_len = ctxl; a.slot = nullptr; a.kc = kc[l]; a.vc = vc[l]; a.cache_T = CT; a.H = H; a.d = d;
         return valle_dec_wave_linear(a, DEC_EPI_QKV, s); };

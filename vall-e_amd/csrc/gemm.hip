@@ -14,6 +14,65 @@
 #define TM 128
 #define LDS_ROW_BYTES 80   // 64 B of k-data + 16 B pad (keeps 16-B alignment, spreads banks)
 
+// Shared epilogue of the dense GEMM kernels: this wave's 64(n) x 64(m) block, acc[i][j] = tile (n i, m j);
+// a lane holds n = nb .. nb+3 (consecutive) for one m.
+template <typename T, int EPI>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[4][4], int nw0, int mw0, int fr, int fq,
+                                              const void* __restrict__ bias, const T* resid, void* Cout,
+                                              int M, int N, int ldc) {
+    // epilogue: lane holds n = nb + 0..3 (consecutive) for one m
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int nb = nw0 + i * 16 + fq * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = mw0 + j * 16 + fr;
+            if (m >= M || nb >= N) continue;
+            f32x4 v = acc[i][j];
+            if constexpr (EPI == VALLE_EPI_F32OUT) {
+                float* C = (float*)Cout;
+                const float* bf = (const float*)bias;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (nb + r < N) C[(size_t)m * ldc + nb + r] = v[r] + (bf ? bf[nb + r] : 0.f);
+            } else if constexpr (EPI == VALLE_EPI_GEGLU) {
+                T* C = (T*)Cout;
+                typedef T vec2 __attribute__((ext_vector_type(2)));
+                vec2 o;
+                // reference: act(gate) and up are each rounded to the storage type before the product
+                o[0] = from_f32<T>(to_f32<T>(from_f32<T>(gelu_erf(to_f32<T>(from_f32<T>(v[0]))))) * to_f32<T>(from_f32<T>(v[1])));
+                o[1] = from_f32<T>(to_f32<T>(from_f32<T>(gelu_erf(to_f32<T>(from_f32<T>(v[2]))))) * to_f32<T>(from_f32<T>(v[3])));
+                *reinterpret_cast<vec2*>(C + (size_t)m * ldc + (nb >> 1)) = o;
+            } else {
+                T* C = (T*)Cout;
+                const T* bt = (const T*)bias;
+                if (nb + 3 < N && (ldc & 3) == 0) {
+                    typedef T vec4 __attribute__((ext_vector_type(4)));
+                    vec4 o;
+                    if constexpr (EPI == VALLE_EPI_RESID) {
+                        const vec4 rr = *reinterpret_cast<const vec4*>(resid + (size_t)m * ldc + nb);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(to_f32<T>(rr[r]) + to_f32<T>(from_f32<T>(v[r])));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r] + (bt ? to_f32<T>(bt[nb + r]) : 0.f));
+                    }
+                    *reinterpret_cast<vec4*>(C + (size_t)m * ldc + nb) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (nb + r >= N) continue;
+                        float o = v[r];
+                        if constexpr (EPI == VALLE_EPI_RESID) o = to_f32<T>(resid[(size_t)m * ldc + nb + r]) + to_f32<T>(from_f32<T>(o));
+                        else if (bt) o += to_f32<T>(bt[nb + r]);
+                        C[(size_t)m * ldc + nb + r] = from_f32<T>(o);
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ X, const T* __restrict__ W,
                                                       const void* __restrict__ bias, const T* resid,
@@ -92,57 +151,100 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ X, c
         __syncthreads();
     }
 
-    // epilogue: lane holds n = nb + 0..3 (consecutive) for one m
+    gemm_epilogue<T, EPI>(acc, n0 + wn * 64, m0 + wm * 64, fr, fq, bias, resid, Cout, M, N, ldc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 dense GEMM with LDS-DMA staging: 128 x 128 tile, BK = 64, two LDS buffers, one barrier per
+// K-step.  global_load_lds writes 64 lanes x 16 B contiguously (1 KiB per wave-instruction = 8 tile
+// rows of 128 B), so the LDS image is linear; bank conflicts of the fragment reads are removed by
+// XOR-swizzling the 16-B chunk index with (row & 7) on the GLOBAL source address and again on the read.
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_glds_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W,
+                                                             const void* __restrict__ bias, const bf16* resid,
+                                                             void* Cout, int M, int N, int K, int ldc) {
+    __shared__ __attribute__((aligned(1024))) char lds[2][2][128 * 128];     // [buf][W | X][128 rows x 128 B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
+
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int nb = n0 + wn * 64 + i * 16 + fq * 4;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging: each operand tile is 16 wave-instructions of 8 rows; this wave issues pieces wave*4 .. +3
+    const bf16* wsrc[4];
+    const bf16* xsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ (row & 7);
+        int n = n0 + row; n = n < N ? n : N - 1;          // rows past the edge re-read the last row (never stored)
+        int m = m0 + row; m = m < M ? m : M - 1;
+        wsrc[j] = W + (size_t)n * K + ch * 8;
+        xsrc[j] = X + (size_t)m * K + ch * 8;
+    }
+    auto stage = [&](int kt, int buf) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + fr;
-            if (m >= M || nb >= N) continue;
-            f32x4 v = acc[i][j];
-            if constexpr (EPI == VALLE_EPI_F32OUT) {
-                float* C = (float*)Cout;
-                const float* bf = (const float*)bias;
+            __builtin_amdgcn_global_load_lds(wsrc[j] + kt * 64, (lds_void*)&lds[buf][0][(wave * 4 + j) * 1024], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(xsrc[j] + kt * 64, (lds_void*)&lds[buf][1][(wave * 4 + j) * 1024], 16, 0, 0);
+        }
+    };
+    // fragment read offsets (bytes) of this lane inside a tile, per 16-row sub-tile i and k-half hf
+    int aoff[4][2], boff[4][2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (nb + r < N) C[(size_t)m * ldc + nb + r] = v[r] + (bf ? bf[nb + r] : 0.f);
-            } else if constexpr (EPI == VALLE_EPI_GEGLU) {
-                T* C = (T*)Cout;
-                typedef T vec2 __attribute__((ext_vector_type(2)));
-                vec2 o;
-                // reference: act(gate) and up are each rounded to the storage type before the product
-                o[0] = from_f32<T>(to_f32<T>(from_f32<T>(gelu_erf(to_f32<T>(from_f32<T>(v[0]))))) * to_f32<T>(from_f32<T>(v[1])));
-                o[1] = from_f32<T>(to_f32<T>(from_f32<T>(gelu_erf(to_f32<T>(from_f32<T>(v[2]))))) * to_f32<T>(from_f32<T>(v[3])));
-                *reinterpret_cast<vec2*>(C + (size_t)m * ldc + (nb >> 1)) = o;
-            } else {
-                T* C = (T*)Cout;
-                const T* bt = (const T*)bias;
-                if (nb + 3 < N && (ldc & 3) == 0) {
-                    typedef T vec4 __attribute__((ext_vector_type(4)));
-                    vec4 o;
-                    if constexpr (EPI == VALLE_EPI_RESID) {
-                        const vec4 rr = *reinterpret_cast<const vec4*>(resid + (size_t)m * ldc + nb);
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(to_f32<T>(rr[r]) + to_f32<T>(from_f32<T>(v[r])));
-                    } else {
+        for (int hf = 0; hf < 2; ++hf) {
+            const int ra = wn * 64 + i * 16 + fr, rb = wm * 64 + i * 16 + fr;
+            aoff[i][hf] = ra * 128 + (((hf * 4 + fq) ^ (ra & 7)) << 4);
+            boff[i][hf] = rb * 128 + (((hf * 4 + fq) ^ (rb & 7)) << 4);
+        }
+    const int nt = K / 64;
+    stage(0, 0);
+    for (int kt = 0; kt < nt; ++kt) {
+        const int buf = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // tile kt landed; everyone is done reading the other buffer
+        if (kt + 1 < nt) stage(kt + 1, buf ^ 1);
+        const char* Ws = lds[buf][0];
+        const char* Xs = lds[buf][1];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r] + (bt ? to_f32<T>(bt[nb + r]) : 0.f));
-                    }
-                    *reinterpret_cast<vec4*>(C + (size_t)m * ldc + nb) = o;
-                } else {
+        for (int hf = 0; hf < 2; ++hf) {
+            bf16x8 a[4], b[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (nb + r >= N) continue;
-                        float o = v[r];
-                        if constexpr (EPI == VALLE_EPI_RESID) o = to_f32<T>(resid[(size_t)m * ldc + nb + r]) + to_f32<T>(from_f32<T>(o));
-                        else if (bt) o += to_f32<T>(bt[nb + r]);
-                        C[(size_t)m * ldc + nb + r] = from_f32<T>(o);
-                    }
-                }
+            for (int i = 0; i < 4; ++i) {
+                a[i] = *reinterpret_cast<const bf16x8*>(Ws + aoff[i][hf]);
+                b[i] = *reinterpret_cast<const bf16x8*>(Xs + boff[i][hf]);
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
+    gemm_epilogue<bf16, EPI>(acc, n0 + wn * 64, m0 + wm * 64, fr, fq, bias, resid, Cout, M, N, ldc);
+}
+
+static int gemm_glds_dispatch(const void* A, const void* W, const void* bias, const void* resid, void* C,
+                              int M, int N, int K, int ldc, int epi, hipStream_t s) {
+    dim3 grid(ceil_div(N, 128), ceil_div(M, 128));
+#define GLDS_CASE(E) case E: gemm_glds_bf16_kernel<E><<<grid, 256, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc); break;
+    switch (epi) {
+        GLDS_CASE(VALLE_EPI_STORE) GLDS_CASE(VALLE_EPI_RESID) GLDS_CASE(VALLE_EPI_GEGLU) GLDS_CASE(VALLE_EPI_F32OUT)
+        default: valle_set_error("valle_gemm: unknown epilogue %d", epi); return VALLE_E_ARG;
+    }
+#undef GLDS_CASE
+    VALLE_LAUNCH_CHECK();
+    return VALLE_OK;
 }
 
 template <typename T>
@@ -169,6 +271,7 @@ extern "C" int valle_gemm(const void* A, const void* W, const void* bias, const 
     VALLE_REQUIRE(ldc >= (epilogue == VALLE_EPI_GEGLU ? N / 2 : N), VALLE_E_ARG, "valle_gemm: ldc %d too small", ldc);
     if (M == 0) return VALLE_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (dtype == VALLE_BF16 && K % 64 == 0 && M >= 64) return gemm_glds_dispatch(A, W, bias, resid, C, M, N, K, ldc, epilogue, s);
     if (dtype == VALLE_BF16) return gemm_dispatch<bf16>(A, W, bias, resid, C, M, N, K, ldc, epilogue, s);
     if (dtype == VALLE_F32) return gemm_dispatch<float>(A, W, bias, resid, C, M, N, K, ldc, epilogue, s);
     valle_set_error("valle_gemm: unknown dtype %d", dtype);
