@@ -91,7 +91,7 @@ int main(int argc, char** argv) {
     auto w_o = [&](int l) { return valle_dec_wave_linear(mkw(att, 0, wo[l], x, x, d, d, d), VALLE_EPI_RESID, s); };
     auto w_gu = [&](int l) { return valle_dec_wave_linear(mkw(x, 1, wgu[l], nullptr, ff, f, 2 * f, d), VALLE_EPI_GEGLU, s); };
     auto w_dn = [&](int l) { return valle_dec_wave_linear(mkw(ff, 0, wdn[l], x, x, d, d, f), VALLE_EPI_RESID, s); };
-    auto w_attn = [&](int l) { return valle_attn_decode_bf16(qkv, 3 * d, kc[l], vc[l], ctxl, nullptr, att, B, H, CT, 1, 1 | (dbg & 48), s); };
+    auto w_attn = [&](int l) { return valle_attn_decode_bf16(qkv, 3 * d, kc[l], vc[l], ctxl, nullptr, att, B, H, CT, 1, 1, s); };
     auto wlayer = [&](int l) { int rc = w_qkv(l); rc |= w_attn(l); rc |= w_o(l); rc |= w_gu(l); rc |= w_dn(l); return rc; };
     auto layer = [&](int l) { int rc = k_qkv(l); rc |= k_attn(l); rc |= k_o(l); rc |= k_gu(l); rc |= k_dn(l); return rc; };
 

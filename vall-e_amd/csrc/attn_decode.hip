@@ -2,7 +2,7 @@
 // (utterance, head) against ctx cached keys -- the KV-cache restatement of the reference's full
 // recompute (models/base.py:521 use_cache=False; SDPA call at models/arch/llama.py:448-456).
 //
-// HBM-bound: every cached K and V row is read exactly once.  One workgroup (8 waves) per
+// HBM-bound: every cached K and V row is read exactly once.  One workgroup (8 or 16 waves) per
 // (utterance, head); the keys of a pass are dealt to the waves in contiguous ranges and ALL of a
 // wave's K and V rows are requested up front (MAXC x 2 x 16 B per lane in flight), then consumed in
 // arrival order.  Lane mapping: 8 lanes share a key (16 B = 8 dims each), so one wave-instruction
@@ -22,9 +22,8 @@ __device__ __forceinline__ float dpp_xor2(float v) { return __builtin_bit_cast(f
 __device__ __forceinline__ float dpp_half_mirror(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)); }
 __device__ __forceinline__ float dpp_ror8(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true)); }
 
-template <int MAXC>
-__global__ __launch_bounds__(512) void attn_decode_bf16_kernel(AttnDecArgs a) {
-    constexpr int NW = 8;
+template <int MAXC, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnDecArgs a) {
     const int b = blockIdx.x, h = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 3, sub = lane & 7;
@@ -143,8 +142,9 @@ int valle_attn_decode_bf16(const void* q, size_t q_row_stride, const void* kcach
     a.ctx_len = ctx_len; a.slot = cache_slot; a.out = (bf16*)out; a.H = H; a.cache_T = cache_T;
     a.ctx_extra = ctx_extra; a.out_frag = out_frag;
     dim3 grid(B, H);
-    if (cache_T <= 8 * 8 * 8) attn_decode_bf16_kernel<8><<<grid, 512, 0, s>>>(a);     // whole context in one pass
-    else attn_decode_bf16_kernel<12><<<grid, 512, 0, s>>>(a);
+    // 16 waves x 6 chunks: 768 keys per pass (measured 2 % faster than 8 waves x 12); short caches in one pass
+    if (cache_T <= 8 * 8 * 8) attn_decode_bf16_kernel<8, 8><<<grid, 512, 0, s>>>(a);
+    else attn_decode_bf16_kernel<6, 16><<<grid, 1024, 0, s>>>(a);
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
 }

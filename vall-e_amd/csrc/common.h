@@ -91,6 +91,9 @@ struct SampleArgs {
     int32_t* seq; int seq_cap; int32_t* seq_len; int32_t* ctx_len; int32_t* stopped;
     int prev_is_seq;            // prev tokens of row i = seq[i*seq_cap .. + seq_len[i])
     uint64_t step;              // added to the Philox offset
+    // optional fused prologue of the NEXT decode step (wave-streaming path): embed the sampled token into the
+    // fragment-order x, its per-tile sums of squares and its RoPE position
+    const bf16* nx_emb; int nx_row0; bf16* nx_x; float* nx_ssq; int32_t* nx_pos; const int32_t* nx_pos0; int nx_d;
 };
 int valle_sample_launch(const SampleArgs& a, int rows, hipStream_t s);
 

@@ -224,11 +224,13 @@ __global__ __launch_bounds__(256) void gemm_glds_bf16_kernel(const bf16* __restr
                 a[i] = *reinterpret_cast<const bf16x8*>(Ws + aoff[i][hf]);
                 b[i] = *reinterpret_cast<const bf16x8*>(Xs + boff[i][hf]);
             }
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
     }
     gemm_epilogue<bf16, EPI>(acc, n0 + wn * 64, m0 + wm * 64, fr, fq, bias, resid, Cout, M, N, ldc);

@@ -228,7 +228,9 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
     for (int step = 0; step < n_steps; ++step) {
         float* lg = logits_out ? logits_out + (size_t)step * B * ld_logits : lg_ws;
         const int ldl = logits_out ? ld_logits : 2048;
-        if (wavepath)
+        if (wavepath && step > 0) {
+            // the previous step's sampler already embedded its token (SampleArgs.nx_*)
+        } else if (wavepath)
             dec_prepare_frag_kernel<<<B, 128, 0, s>>>((const bf16*)m->emb, st->resp_emb_row0, st->seq, st->max_steps, st->seq_len, st->resp_pos0, xf, ssq, pos, d);
         else if (dt == VALLE_BF16)
             dec_prepare_kernel<bf16><<<B, 128, 0, s>>>((const bf16*)m->emb, st->resp_emb_row0, st->seq, st->max_steps, st->seq_len, st->resp_pos0, (bf16*)x, pos, cu, d, B);
@@ -303,7 +305,11 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
         if (sp == nullptr) break;   // logits only: the caller samples and appends (CFG path)
         SampleArgs sa{};
         sa.logits = lg; sa.ld = ldl; sa.vocab = st->vocab; sa.nar_mode = 0; sa.p = *sp;
-        sa.ids = pos;  // scratch: the token also lands in seq
+        sa.ids = wavepath ? cu : pos;  // scratch: the token also lands in seq
+        if (wavepath && step + 1 < n_steps) {
+            sa.nx_emb = (const bf16*)m->emb; sa.nx_row0 = st->resp_emb_row0; sa.nx_x = xf; sa.nx_ssq = ssq;
+            sa.nx_pos = pos; sa.nx_pos0 = st->resp_pos0; sa.nx_d = d;
+        }
         sa.scores = st->scores;
         sa.seq = st->seq; sa.seq_cap = st->max_steps; sa.seq_len = st->seq_len; sa.ctx_len = st->ctx_len; sa.stopped = st->stopped;
         sa.prev_is_seq = 1; sa.step = (uint64_t)step;

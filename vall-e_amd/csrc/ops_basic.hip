@@ -5,7 +5,6 @@
 //   attn_rowwise   models/arch/llama.py:448-456 (one query row per workgroup; parity path + decode)
 #include "common.h"
 #include <stdarg.h>
-#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 void valle_set_error(const char* fmt, ...) {
@@ -367,14 +366,9 @@ int valle_attn_decode_launch(const void* qkv, const void* kcache, const void* vc
     a.out = out; a.out_row_stride = d; a.causal = 1; a.B = B; a.ctx_extra = ctx_extra;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(B, H);
-    static int variant = -1;
-    if (variant < 0) { const char* e = getenv("VALLE_ATTN_VARIANT"); variant = e ? atoi(e) : 0; }
-    if (dtype == VALLE_BF16 && variant == 1) attn_rowwise_kernel<bf16, true, 4, 4><<<grid, 256, 0, s>>>(a);
-    else if (dtype == VALLE_BF16 && variant == 2) attn_rowwise_kernel<bf16, true, 4, 8><<<grid, 256, 0, s>>>(a);
-    else if (dtype == VALLE_BF16 && variant == 3) attn_rowwise_kernel<bf16, true, 16, 4><<<grid, 1024, 0, s>>>(a);
-    else if (dtype == VALLE_BF16 && variant == 4) attn_rowwise_kernel<bf16, true, 8, 2><<<grid, 512, 0, s>>>(a);
-    else if (dtype == VALLE_BF16) attn_rowwise_kernel<bf16, true, 8, 8><<<grid, 512, 0, s>>>(a);
-    else if (dtype == VALLE_F32) attn_rowwise_kernel<float, true, 8, 4><<<grid, 512, 0, s>>>(a);
+    if (dtype == VALLE_BF16)      // the streaming bf16 kernel (attn_decode.hip), row-major output
+        return valle_attn_decode_bf16(qkv, (size_t)3 * d, kcache, vcache, ctx_len, cache_slot, out, B, H, cache_T, ctx_extra, 0, s);
+    if (dtype == VALLE_F32) attn_rowwise_kernel<float, true, 8, 4><<<grid, 512, 0, s>>>(a);
     else VALLE_REQUIRE(false, VALLE_E_ARG, "valle_attn_decode: unknown dtype %d", dtype);
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;

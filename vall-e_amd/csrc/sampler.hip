@@ -271,6 +271,19 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
         }
     }
     (void)s_f;
+    if (a.nx_x != nullptr) {        // = dec_prepare_frag_kernel (model.hip) for the token just appended
+        const bf16* src = a.nx_emb + (size_t)(a.nx_row0 + tok) * a.nx_d;
+        for (int c = tid * 8; c < a.nx_d; c += SAMP_THREADS * 8) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c);
+            float q2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q2 = fmaf((float)v[e], (float)v[e], q2);
+            q2 += __shfl_xor(q2, 1, 64);
+            *reinterpret_cast<bf16x8*>(a.nx_x + ((((c >> 5) << 6) + (((c >> 3) & 3) << 4) + item) << 3)) = v;
+            if ((tid & 1) == 0) a.nx_ssq[(size_t)item * (a.nx_d >> 4) + (c >> 4)] = q2;
+        }
+        if (tid == 0) a.nx_pos[item] = (a.nx_pos0 ? a.nx_pos0[item] : 0) + n_prev;   // position of token index n_prev
+    }
 }
 
 int valle_sample_launch(const SampleArgs& a, int rows, hipStream_t s) {
