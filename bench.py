@@ -35,6 +35,7 @@ from vall_e_amd.synth import synth_batch         # noqa: E402
 from vall_e_amd.weights import synth_state_dict  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 FRAME_RATE = 75.0
 
 
@@ -46,6 +47,14 @@ def decode_step_bytes(cfg, B, ctx):
     norms = (2 * L + 1) * d * 2
     kv_row = L * 2 * d * 2
     return weights + head + norms + sum(c * kv_row for c in ctx) + B * kv_row + B * d * 2
+
+
+def dense_pass_flops(cfg, lens, out_rows, vocab):
+    """Algorithmic FLOPs of one dense pass over packed utterances: linears 2*params per
+    token, causal attention 2*T^2*d per layer and utterance, head only on the rows that are used."""
+    d, L, ff = cfg.dim, cfg.layers, cfg.dim * cfg.ffn
+    per_tok = 2 * L * (4 * d * d + 3 * d * ff)
+    return sum(lens) * per_tok + sum(2 * t * t * d * L for t in lens) + 2 * out_rows * d * vocab
 
 
 def cpu_baseline(cfg, sd, phns, proms, langs, R):
@@ -113,13 +122,19 @@ def main():
     model = get_model(cfg).load_state_dict(sd).to(dev, torch.bfloat16)
     phns, proms, langs = synth_batch(1234 + rank, B, n_phn=80, n_prom=225)
     tasks = ["tts"] * B
-    prof = []
+    prof, nar_prof = [], []
 
     def step(profile=None):
         codes = model(task_list=tasks, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=R,
                       temperature=0.0, step_chunk=R, profile=profile)
+        if profile is not None:
+            n0, n1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n0.record()
         full = model(task_list=tasks, phns_list=phns, proms_list=proms, lang_list=langs,
                      resps_list=codes, temperature=0.0)
+        if profile is not None:
+            n1.record()
+            nar_prof.append((n0, n1))
         out = torch.stack([f.to(torch.int16) for f in full])            # (B, R, 8)
         if dist is not None:
             raw = out.view(torch.uint8)                                 # RCCL has no int16: ship the bytes
@@ -164,6 +179,15 @@ def main():
                     "kernel": "AR decode step (valle_ar_decode: all kernels of one step)",
                     "us_per_decode_step": round(dec_ms * 1e3 / dec_steps, 2),
                     "algorithmic_bytes_per_step": int(dec_bytes / dec_steps)}
+    dense = None
+    if nar_prof:
+        T = int(phns[0].shape[0]) + int(proms[0].shape[0]) + R + 6
+        fl = 7 * dense_pass_flops(cfg, [T] * B, B * R, cfg.audio_tokens)
+        nar_ms = sum(a.elapsed_time(b) for a, b in nar_prof) / len(nar_prof)
+        tf = fl / (nar_ms * 1e-3) / 1e12
+        dense = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "what": f"7 NAR levels, {B} x {T} tokens each, host time included",
+                 "ms": round(nar_ms, 2)}
     if rank == 0:
         line = {
             "metric": "RVQ frames/sec (all levels)", "value": round(frames / elapsed, 2), "unit": "frames/s",
@@ -174,6 +198,7 @@ def main():
                        "global_batch": world * B, "frames_per_utterance": R, "parallelism": f"utterance-sharded x{world}"},
             "rtf": round((elapsed / args.steps) / (R / FRAME_RATE), 5),
             "roofline": roofline,
+            "dense": dense,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, phns, proms, langs, R)

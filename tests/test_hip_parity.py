@@ -359,3 +359,62 @@ def test_tts_batched_inference_matches_oracle(gpu_device):
         assert len(codes) == len(mine)
         seen += mine
     assert sorted(seen) == list(range(5))
+
+
+# ------------------------------------------------------------------- full-size configurations
+def test_longform_b32_sampling_properties(gpu_device):
+    """BASELINE configs[4] at full size (batch 32, ~2.5k-frame KV cache, repetition/length penalties,
+    top-k/top-p, temperature 1): sampled codes are not comparable across implementations,
+    so the checks are size-independent properties -- every token lies in the top-k set of its own
+    step's logits, a fixed seed reproduces the sequence, and the cached last-step logits equal a dense
+    recompute of the same 2.5k-token sequences within the bf16 tolerance."""
+    from vall_e_amd.synth import synth_batch
+    B, R = 32, 2250
+    phns, proms, langs = synth_batch(4321, B, n_phn=80, n_prom=225)
+    m = hip_model("full", torch.bfloat16, stop_bias=-30000.0)
+    kw = dict(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, temperature=1.0, top_k=50, top_p=0.9,
+              repetition_penalty=1.1, repetition_penalty_decay=0.0, length_penalty=0.5, seed=7,
+              top_no=0.0)   # as the reference's CLI/web UI pass it: the default top_no=1.0 turns every top-k row into NaNs (samplers.py:164-172)
+    codes, logits = m(max_duration=64, return_logits=True, step_chunk=16, **kw)
+    for step in (1, 17, 63):
+        top = logits[step].topk(50, dim=-1).indices.cpu()
+        for i in range(B):
+            assert int(codes[i][step]) in top[i].tolist(), (step, i)
+    again = m(max_duration=64, step_chunk=64, **kw)
+    for a, b in zip(codes, again):
+        assert torch.equal(a, b)
+    long = m(max_duration=R, step_chunk=R, **kw)
+    assert all(c.shape == (R,) and int(c.min()) >= 0 and int(c.max()) < 1024 for c in long)
+    long2 = m(max_duration=R, step_chunk=500, **kw)    # same seed, other chunking of the step loop: same draw
+    for a, b in zip(long, long2):
+        assert torch.equal(a, b)
+    # KV-cache decode at ctx ~2.5k vs dense recompute, on a 4-utterance slice (greedy so both see one sequence)
+    sl = slice(0, 4)
+    g, lg = m(task_list=["tts"] * 4, phns_list=phns[sl], proms_list=proms[sl], lang_list=langs[sl], max_duration=R,
+              temperature=0.0, return_logits=True, step_chunk=512)
+    dense = m.forward_super(dict(phns_list=phns[sl], lang_list=langs[sl], proms_list=proms[sl],
+                                 resps_list=[c[:R - 1] for c in g]), quant_levels=[0])
+    want = torch.stack([l[-1] for l in dense.logits])
+    assert rel_l2(lg[R - 1], want) < 4e-2
+
+
+def test_narlen_b64_properties(gpu_device):
+    """BASELINE configs[2] at full batch (64 utterances, NAR-len demasking + 7 NAR levels, cfg 2.5/0.75),
+    reduced to 6 demasking steps of 150 frames: no mask token survives, codes are in range, the run is
+    reproducible, and utterance i of the batch equals the same utterance run alone (batch independence:
+    the packed layout must not leak across utterances)."""
+    from vall_e_amd.synth import synth_batch
+    B, R = 64, 150
+    phns, proms, langs = synth_batch(99, B, n_phn=80, n_prom=225, ragged=True)
+    m = hip_model("full", torch.bfloat16)
+    kw = dict(max_steps=6, temperature=0.0, cfg_strength=2.5, cfg_rescale=0.75)
+    out = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, len_list=[R] * B, **kw)
+    assert len(out) == B
+    for r in out:
+        assert r.shape == (R, 8) and int(r.min()) >= 0 and int(r.max()) < 1024
+    again = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, len_list=[R] * B, **kw)
+    for a, b in zip(out, again):
+        assert torch.equal(a, b)
+    solo = m(task_list=["tts"], phns_list=phns[5:6], proms_list=proms[5:6], lang_list=langs[5:6], len_list=[R], **kw)
+    agree = (solo[0] == out[5]).float().mean().item()
+    assert agree > 0.9, agree          # bf16 GEMM tiles see different neighbours; greedy near-ties may flip a few codes
