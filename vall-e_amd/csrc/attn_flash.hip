@@ -2,8 +2,8 @@
 // head_dim 64, token-packed variable-length batches.  Replaces SDPA + additive mask at
 // models/arch/llama.py:448-456 / :689-730.
 //
-// One workgroup = 4 waves = 64 query rows of one (utterance, head); K/V tiles of 64 keys go
-// through LDS (register-prefetched one tile ahead).  Per wave the score tile is computed
+// One workgroup = 4 waves = 64 or 128 query rows of one (utterance, head); K/V tiles of 64 keys go
+// through a double-buffered LDS image (register-prefetched one tile ahead).  Per wave the score tile is computed
 // TRANSPOSED, S^T = K.Q^T (MFMA A = K rows, B = Q rows): a lane then owns ONE query (its
 // column) and 16 keys of the tile, so the online-softmax state (m, l) and the rescale factor are
 // per-lane scalars and P^T is already the B operand of O^T += V^T.P^T -- P never leaves
@@ -15,30 +15,44 @@
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
+// QB = query blocks of 16 per wave: a workgroup covers 64*QB queries; every K/V fragment read from LDS
+// feeds QB MFMAs.  K/V tiles are double-buffered in LDS: one barrier per tile.
+template <int QB>
 __global__ __launch_bounds__(256) void attn_flash_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                               const int32_t* __restrict__ cu, int H, int causal) {
+    constexpr int QT = 64 * QB;                               // queries per workgroup
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int start = cu[b], T = cu[b + 1] - start;
-    if (qt * 64 >= T) return;
+    if (qt * QT >= T) return;
     const int d = H * 64, ld = 3 * d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    __shared__ __attribute__((aligned(16))) bf16 Ks[64 * FA_ROW];
-    __shared__ __attribute__((aligned(16))) bf16 Vs[64 * FA_ROW];
+    __shared__ __attribute__((aligned(16))) bf16 Ks[2][64 * FA_ROW];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[2][64 * FA_ROW];
 
-    const int q = qt * 64 + wave * 16 + fr;                 // this lane's query (column of S^T)
-    const int qc = q < T ? q : T - 1;
-    const bf16* qp = qkv + (size_t)(start + qc) * ld + h * 64 + fq * 8;
-    bf16x8 qf[2];
-    qf[0] = *reinterpret_cast<const bf16x8*>(qp);
-    qf[1] = *reinterpret_cast<const bf16x8*>(qp + 32);
-
-    const int n_kt = causal ? qt + 1 : (T + 63) / 64;
-    float m = -INFINITY, l = 0.f;
-    f32x4 o[4];
+    int q[QB];                                                // this lane's queries (columns of S^T)
+    bf16x8 qf[QB][2];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float sc = 0.125f * 1.4426950408889634f;          // 1/sqrt(64) * log2(e)
+    for (int j = 0; j < QB; ++j) {
+        q[j] = qt * QT + (wave * QB + j) * 16 + fr;
+        const int qc = q[j] < T ? q[j] : T - 1;
+        const bf16* qp = qkv + (size_t)(start + qc) * ld + h * 64 + fq * 8;
+        qf[j][0] = *reinterpret_cast<const bf16x8*>(qp);
+        qf[j][1] = *reinterpret_cast<const bf16x8*>(qp + 32);
+    }
+    const int q_hi = qt * QT + (wave * QB + QB) * 16 - 1;     // largest query of this wave
+    const int q_lo = qt * QT + wave * QB * 16;                // smallest
+    const int last_q = min(qt * QT + QT, T) - 1;              // largest query of the workgroup
+    const int n_kt = causal ? last_q / 64 + 1 : (T + 63) / 64;
+    float m[QB], l[QB];
+    f32x4 o[QB][4];
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        m[j] = -INFINITY; l[j] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[j][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const float sc = 0.125f * 1.4426950408889634f;            // 1/sqrt(64) * log2(e)
 
     uint4 kr[2], vr[2];
     auto gload = [&](int kt) {
@@ -54,65 +68,74 @@ __global__ __launch_bounds__(256) void attn_flash_bf16_kernel(const bf16* __rest
     };
     gload(0);
     for (int kt = 0; kt < n_kt; ++kt) {
-        __syncthreads();                                     // the previous tile is fully consumed
+        bf16* Kb = Ks[kt & 1];
+        bf16* Vb = Vs[kt & 1];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-            *reinterpret_cast<uint4*>(&Ks[row * FA_ROW + ch * 8]) = kr[i];
-            *reinterpret_cast<uint4*>(&Vs[row * FA_ROW + ch * 8]) = vr[i];
+            *reinterpret_cast<uint4*>(&Kb[row * FA_ROW + ch * 8]) = kr[i];
+            *reinterpret_cast<uint4*>(&Vb[row * FA_ROW + ch * 8]) = vr[i];
         }
-        __syncthreads();
+        __syncthreads();          // tile kt visible; the other buffer was last read in iteration kt-1, which every wave has left
         if (kt + 1 < n_kt) gload(kt + 1);
-        // ---- S^T = K . Q^T : 4 key sub-tiles x 2 k-steps
-        f32x4 st[4];
+        if (causal && kt * 64 > q_hi) continue;              // wave-uniform: this wave's queries see none of these keys
+        const bool diag = causal && (kt * 64 + 63 > q_lo);   // some (query, key) pair of this wave is masked
+        const bool tail = (kt + 1) * 64 > T;
+        // ---- S^T = K . Q^T : 4 key sub-tiles x 2 k-steps, each K fragment feeds QB query blocks
+        f32x4 st[QB][4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            st[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&Kb[(nt * 16 + fr) * FA_ROW + fq * 8]);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&Kb[(nt * 16 + fr) * FA_ROW + 32 + fq * 8]);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ks[(nt * 16 + fr) * FA_ROW + ks * 32 + fq * 8]);
-                st[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], st[nt], 0, 0, 0);
+            for (int j = 0; j < QB; ++j) {
+                st[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[j][0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                st[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[j][1], st[j][nt], 0, 0, 0);
             }
         }
-        // ---- scale, mask, online softmax (state is per lane = per query)
-        const bool diag = causal ? (kt == qt) : false;
-        const bool tail = (kt + 1) * 64 > T;
-        float mx = -INFINITY;
+        // ---- mask (edge tiles only), online softmax in the log2 domain; state is per lane = per query
+        bf16x8 pf[QB][2];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int j = 0; j < QB; ++j) {
+            if (diag || tail) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 64 + nt * 16 + fq * 4 + r;
-                float v = st[nt][r] * sc;
-                if ((tail && key >= T) || (diag && key > q)) v = -INFINITY;
-                st[nt][r] = v;
-                mx = fmaxf(mx, v);
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 64 + nt * 16 + fq * 4 + r;
+                        if ((tail && key >= T) || (diag && key > q[j])) st[j][nt][r] = -INFINITY;
+                    }
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m - mn);
-        float ls = 0.f;
+            float mx = fmaxf(fmaxf(st[j][0][0], st[j][0][1]), fmaxf(st[j][0][2], st[j][0][3]));
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 1; nt < 4; ++nt)
+                mx = fmaxf(mx, fmaxf(fmaxf(st[j][nt][0], st[j][nt][1]), fmaxf(st[j][nt][2], st[j][nt][3])));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m[j], mx * sc);            // sc > 0: max commutes with the scale
+            const float ms = (mn == -INFINITY) ? 0.f : mn;    // fully masked so far (rows past T): keep arguments finite
+            const float alpha = __builtin_amdgcn_exp2f(m[j] - ms);
+            float ls = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(st[nt][r] - mn);
-                st[nt][r] = p;
-                ls += p;
-            }
-        l = l * alpha + ls;
-        m = mn;
+            for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(st[j][nt][r], sc, -ms));
+                    st[j][nt][r] = p;
+                    ls += p;
+                }
+            l[j] = l[j] * alpha + ls;
+            m[j] = mn;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
-        // ---- P^T as the B operand: k-slot (fq, j) <-> key 32ks + 16*(j>>2) + 4fq + (j&3)
-        bf16x8 pf[2];
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+                for (int r = 0; r < 4; ++r) o[j][dt][r] *= alpha;
+            // P^T as the B operand: k-slot (fq, e) <-> key 32ks + 16*(e>>2) + 4fq + (e&3)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf[ks][j] = (bf16)st[2 * ks + (j >> 2)][j & 3];
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[j][ks][e] = (bf16)st[j][2 * ks + (e >> 2)][e & 3];
+        }
         // ---- O^T += V^T . P^T : A operand through the transposing LDS read, same key mapping
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -120,34 +143,45 @@ __global__ __launch_bounds__(256) void attn_flash_bf16_kernel(const bf16* __rest
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int col = dt * 16 + (fr & 3) * 4;
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)&Vs[krow * FA_ROW + col]);
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)&Vs[(krow + 16) * FA_ROW + col]);
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)&Vb[krow * FA_ROW + col]);
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)&Vb[(krow + 16) * FA_ROW + col]);
                 bf16x8 vt;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { vt[j] = lo[j]; vt[4 + j] = hi[j]; }
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pf[ks], o[dt], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) { vt[e] = lo[e]; vt[4 + e] = hi[e]; }
+#pragma unroll
+                for (int j = 0; j < QB; ++j)
+                    o[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pf[j][ks], o[j][dt], 0, 0, 0);
             }
         }
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    if (q < T) {
-        const float inv = 1.0f / l;
-        bf16* op = out + (size_t)(start + q) * d + h * 64 + fq * 4;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            bf16x4 ov;
+    for (int j = 0; j < QB; ++j) {
+        float lt = l[j];
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        if (q[j] < T) {
+            const float inv = 1.0f / lt;
+            bf16* op = out + (size_t)(start + q[j]) * d + h * 64 + fq * 4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ov[r] = (bf16)(o[dt][r] * inv);
-            *reinterpret_cast<bf16x4*>(op + dt * 16) = ov;
+            for (int dt = 0; dt < 4; ++dt) {
+                bf16x4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (bf16)(o[j][dt][r] * inv);
+                *reinterpret_cast<bf16x4*>(op + dt * 16) = ov;
+            }
         }
     }
 }
 
 int valle_attn_flash_bf16(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int max_T, int H, int causal,
                           hipStream_t s) {
-    dim3 grid(ceil_div(max_T, 64), H, B);
-    attn_flash_bf16_kernel<<<grid, 256, 0, s>>>((const bf16*)qkv, (bf16*)out, cu_seqlens, H, causal);
+    if (max_T > 256) {
+        dim3 grid(ceil_div(max_T, 128), H, B);
+        attn_flash_bf16_kernel<2><<<grid, 256, 0, s>>>((const bf16*)qkv, (bf16*)out, cu_seqlens, H, causal);
+    } else {
+        dim3 grid(ceil_div(max_T, 64), H, B);
+        attn_flash_bf16_kernel<1><<<grid, 256, 0, s>>>((const bf16*)qkv, (bf16*)out, cu_seqlens, H, causal);
+    }
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
 }
