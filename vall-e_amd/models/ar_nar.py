@@ -30,6 +30,16 @@ def clamp(n, lo, hi):
     return max(lo, min(n, hi))
 
 
+def _host_codes(tensors):
+    """list of (R_i, L) integer tensors -> list of int64 numpy arrays, with ONE device->host copy when
+    they live on a GPU (a .cpu() per utterance costs ~40 us of synchronisation each)."""
+    if all(isinstance(t, torch.Tensor) and t.is_cuda for t in tensors) and len({t.shape[1:] for t in tensors}) == 1:
+        flat = torch.cat([t.long() for t in tensors]).cpu().numpy()
+        cuts = np.cumsum([0] + [t.shape[0] for t in tensors])
+        return [flat[cuts[i]:cuts[i + 1]] for i in range(len(tensors))]
+    return [_np(t) for t in tensors]
+
+
 class AR_NAR(Base):
     # ---------------------------------------------------------------- lower-level surface
     def forward_super(self, inputs, quant_levels=None, state=None, output_attentions=False, output_hidden_states=False):
@@ -235,7 +245,9 @@ class AR_NAR(Base):
         for i, r in enumerate(resps_list):
             if r.dim() == 1:
                 resps_list[i] = r.unsqueeze(-1)
-        prev = [r.to(self.device).long() for r in resps_list]
+        # host mirror of the codes: sequence planning and the sampler's `prev` tables are integer
+        # bookkeeping done on the host; one device->host copy here and one per level (the new column)
+        prev = _host_codes(resps_list)
         sp = self.sample_params(**kw)
         null_text = [torch.tensor([1, 2]) for _ in range(B)]
         for n in range(max_levels):
@@ -254,9 +266,11 @@ class AR_NAR(Base):
                 self.cfg_combine(logits, null, V, off, cfg_strength, cfg_rescale)
             sp.offset = 1000 + n
             ids, _ = self.sample_rows(logits, V, off, prev, nar_mode=1, params=sp)
-            ids = ids.long()
-            prev = [torch.cat([p, ids[off[i]:off[i + 1], None]], dim=-1) for i, p in enumerate(prev)]
-        return prev
+            ids = ids.cpu().numpy().astype(np.int64)
+            prev = [np.concatenate([p, ids[off[i]:off[i + 1], None]], axis=-1) for i, p in enumerate(prev)]
+        flat = torch.from_numpy(np.concatenate(prev)).to(self.device)                # one upload, split into views
+        cuts = np.cumsum([0] + [p.shape[0] for p in prev])
+        return [flat[cuts[i]:cuts[i + 1]] for i in range(B)]
 
     # ------------------------------------------------------------------------------- NAR-len
     def forward_nar_masked(self, task_list=None, phns_list=None, proms_list=None, resps_list=None, lang_list=None,
