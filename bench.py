@@ -172,10 +172,19 @@ def main():
         for j in range(n):
             dec_bytes += decode_step_bytes(cfg, B, [c + j for c in ctx0])
     roofline = None
+    traffic, traffic_src = None, None
+    pmc = ROOT / "profiles" / "r1_pmc_decode_layer.json"
+    if dec_steps and pmc.exists():
+        # HBM bytes per decode step from the PMC passes committed under profiles/ (FETCH_SIZE x2 on gfx950 +
+        # WRITE_SIZE, collected on the same kernels at the bench's mean context): measured / algorithmic of one
+        # layer, applied to this run's algorithmic bytes per step
+        ratio = json.loads(pmc.read_text())["layer_traffic_over_algorithmic"]
+        traffic = int(dec_bytes / dec_steps * ratio)
+        traffic_src = f"profiles/{pmc.name}: measured/algorithmic = {ratio} per layer at ctx 537"
     if dec_steps:
         achieved = dec_bytes / (dec_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": "AR decode step (valle_ar_decode: all kernels of one step)",
                     "us_per_decode_step": round(dec_ms * 1e3 / dec_steps, 2),
                     "algorithmic_bytes_per_step": int(dec_bytes / dec_steps)}

@@ -52,6 +52,7 @@ int main(int argc, char** argv) {
     const int ctx = argc > 2 ? atoi(argv[2]) : 536;
     const int CT = 768;
     const int dbg = argc > 3 ? atoi(argv[3]) : 0;
+    const bool force_eager = argc > 4 && atoi(argv[4]) != 0;   // counter runs: one dispatch record per kernel
     std::vector<bf16*> wqkv(L), wo(L), wgu(L), wdn(L), kc(L), vc(L);
     const size_t per = (size_t)B * H * CT * 64;
     for (int l = 0; l < L; ++l) {
@@ -72,7 +73,7 @@ int main(int argc, char** argv) {
     { std::vector<int32_t> hc(B, ctx); CK(hipMemcpy(ctxl, hc.data(), B * 4, hipMemcpyHostToDevice)); }
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const int reps = 20;
+    const int reps = force_eager ? 2 : 20;
 
     auto mk = [&](const bf16* xx, const bf16* norm, const bf16* W, const bf16* resid, void* out, int ldo, int N, int K) {
         DecArgs a{}; a.x = xx; a.norm_w = norm; a.eps = 1e-6f; a.W = W; a.resid = resid; a.out = out; a.ldo = ldo; a.B = B; a.N = N; a.K = K; a.dbg = dbg; return a; };
@@ -98,6 +99,7 @@ int main(int argc, char** argv) {
     // times `fn(l)` for l in 0..L-1 as one dependent chain; graph = captured once, replayed
     auto timeit = [&](const char* name, double mb, bool graph, auto fn) -> int {
         float ms;
+        if (force_eager) graph = false;
         for (int l = 0; l < L; ++l) RC(fn(l));
         CK(hipStreamSynchronize(s));
         if (!graph) {
