@@ -107,3 +107,28 @@ def test_state_dict_spec_matches_reference_names():
     spec = host_model("full").state_dict_spec()
     assert sum(int(np.prod(s)) for s in spec.values()) == 237_968_641      # parameters as instantiated
     assert spec["resps_emb.embeddings.0.weight"] == (1025, 1024) and spec["classifiers.proj.9.weight"] == (256, 1024)
+
+
+def test_weights_file_roundtrip_in_reference_format(tmp_path):
+    """A file written the way Engines.export does (state dict + JSON `config`/`stats` metadata,
+    vall_e/engines/base.py:356-401, utils/io.py:92-104) loads back into the same config and tensors."""
+    import torch
+    from vall_e_amd.config import tiny_model
+    from vall_e_amd.models import get_model
+    from vall_e_amd.utils.io import load_model_file, torch_load, torch_save
+    from vall_e_amd.weights import synth_state_dict
+    cfg = tiny_model()
+    sd = synth_state_dict(cfg, 5)
+    path = tmp_path / "fp32.sft"
+    torch_save({"module": sd, "config": cfg.to_dict(), "stats": {"global_step": 3}, "userdata": {}}, path)
+    blob = torch_load(path)
+    assert blob["stats"] == {"global_step": 3} and blob["config"]["experimental"]["split_classifiers"] is True
+    cfg2, sd2 = load_model_file(path)
+    assert cfg2.to_dict() == cfg.to_dict()
+    assert list(sd2) == sorted(sd) or set(sd2) == set(sd)
+    for k in sd:
+        assert torch.equal(sd[k], sd2[k])
+    get_model(cfg2).load_state_dict(sd2)          # shapes and names accepted
+    import pytest
+    with pytest.raises(NotImplementedError):
+        torch_load(tmp_path / "model.pth")

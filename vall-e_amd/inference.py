@@ -14,6 +14,8 @@ round-robin to ranks and ``gather_codes`` returns every rank's codes with one al
 """
 from __future__ import annotations
 
+from pathlib import Path
+
 import numpy as np
 import torch
 
@@ -99,6 +101,14 @@ class TTS:
             raise NotImplementedError("LoRA is outside the built path")
         if attention not in (None, "auto", "valle_hip"):
             raise NotImplementedError(f"attention backend {attention!r}: the HIP path has one attention implementation")
+        if isinstance(config, (str, Path)):
+            # inference.py:47-89: a weights file carries its own model config in its metadata; a YAML names the model
+            path = Path(config)
+            if path.suffix in (".yaml", ".yml"):
+                config = ModelConfig.from_yaml(path)
+            else:
+                from .utils.io import load_model_file
+                config, state_dict = load_model_file(path)
         self.config = config if isinstance(config, ModelConfig) else repo_default_model()
         self.device = torch.device(device if device is not None else "cuda")
         self.dtype = dtype if dtype is not None else torch.float32        # data/config.yaml:118 weight_dtype float32
