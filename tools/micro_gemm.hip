@@ -1,0 +1,46 @@
+// Dev micro-benchmark (not part of the library): the dense-pass GEMM shapes of one NAR level
+// (B=16 x T=761 = 12,176 rows) through valle_gemm, bf16, random operands.
+#include "../vall-e_amd/csrc/common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+__global__ void fill_rand(uint16_t* p, size_t n, uint32_t seed) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        p[i] = (uint16_t)(((h & 1u) << 15) | ((118u + ((h >> 1) & 7u)) << 7) | ((h >> 8) & 0x7fu));
+    }
+}
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 12176;
+    struct Shape { const char* name; int N, K, epi; } shapes[] = {
+        {"qkv   N=3072 K=1024 store", 3072, 1024, VALLE_EPI_STORE}, {"o     N=1024 K=1024 resid", 1024, 1024, VALLE_EPI_RESID},
+        {"gu    N=8192 K=1024 geglu", 8192, 1024, VALLE_EPI_GEGLU}, {"down  N=1024 K=4096 resid", 1024, 4096, VALLE_EPI_RESID}};
+    bf16 *A, *W, *C, *R;
+    CK(hipMalloc(&A, (size_t)M * 4096 * 2)); CK(hipMalloc(&W, (size_t)8192 * 4096 * 2));
+    CK(hipMalloc(&C, (size_t)M * 8192 * 2)); CK(hipMalloc(&R, (size_t)M * 8192 * 2));
+    fill_rand<<<1024, 256>>>((uint16_t*)A, (size_t)M * 4096, 1); fill_rand<<<1024, 256>>>((uint16_t*)W, (size_t)8192 * 4096, 2);
+    fill_rand<<<1024, 256>>>((uint16_t*)R, (size_t)M * 8192, 3);
+    CK(hipDeviceSynchronize());
+    hipStream_t s; CK(hipStreamCreate(&s));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    double tot = 0;
+    for (auto& sh : shapes) {
+        const int ldc = sh.epi == VALLE_EPI_GEGLU ? sh.N / 2 : sh.N;
+        for (int i = 0; i < 3; ++i)
+            if (valle_gemm(A, W, nullptr, R, C, M, sh.N, sh.K, ldc, sh.epi, VALLE_BF16, s)) { printf("error: %s\n", valle_last_error()); return 1; }
+        CK(hipStreamSynchronize(s));
+        const int reps = 20;
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < reps; ++i) valle_gemm(A, W, nullptr, R, C, M, sh.N, sh.K, ldc, sh.epi, VALLE_BF16, s);
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / reps, tf = 2.0 * M * sh.N * sh.K / us * 1e-6;
+        printf("%-28s %8.1f us  %7.1f TFLOP/s\n", sh.name, us, tf);
+        tot += us;
+    }
+    printf("layer GEMMs total %.1f us\n", tot);
+    return 0;
+}
