@@ -62,9 +62,9 @@ def test_rmsnorm(gpu_device, dtype):
     torch.testing.assert_close(out.cpu().float(), want.float(), rtol=tol, atol=tol)
 
 
-@pytest.mark.parametrize("dtype,epi", [(torch.float32, 0), (torch.bfloat16, 0), (torch.float32, 1), (torch.bfloat16, 2), (torch.float32, 2),
+@pytest.mark.parametrize("dtype,epi", [(torch.float32, 0), (torch.bfloat16, 0), (torch.float32, 1), (torch.bfloat16, 1), (torch.bfloat16, 2), (torch.float32, 2),
                                        (torch.bfloat16, 3), (torch.float32, 3)])
-@pytest.mark.parametrize("shape", [(200, 384, 256), (129, 1025, 1024), (16, 1024, 4096)])
+@pytest.mark.parametrize("shape", [(200, 384, 256), (129, 1025, 1024), (16, 1024, 4096), (300, 1000, 512)])
 def test_gemm_epilogues(gpu_device, dtype, epi, shape):
     from vall_e_amd import _lib as L
     M, N, K = shape

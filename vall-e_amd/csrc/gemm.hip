@@ -16,16 +16,16 @@
 
 // Shared epilogue of the dense GEMM kernels: this wave's 64(n) x 64(m) block, acc[i][j] = tile (n i, m j);
 // a lane holds n = nb .. nb+3 (consecutive) for one m.
-template <typename T, int EPI>
-__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[4][4], int nw0, int mw0, int fr, int fq,
+template <typename T, int EPI, int NI = 4, int MJ = 4>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[NI][MJ], int nw0, int mw0, int fr, int fq,
                                               const void* __restrict__ bias, const T* resid, void* Cout,
                                               int M, int N, int ldc) {
     // epilogue: lane holds n = nb + 0..3 (consecutive) for one m
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int nb = nw0 + i * 16 + fq * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < MJ; ++j) {
             const int m = mw0 + j * 16 + fr;
             if (m >= M || nb >= N) continue;
             f32x4 v = acc[i][j];
@@ -236,8 +236,87 @@ __global__ __launch_bounds__(256) void gemm_glds_bf16_kernel(const bf16* __restr
     gemm_epilogue<bf16, EPI>(acc, n0 + wn * 64, m0 + wm * 64, fr, fq, bias, resid, Cout, M, N, ldc);
 }
 
+// Narrow-N variant (o_proj / down_proj, N = d_model): 64(n) x 128(m) tile, the 4 waves side by side along m
+// (each 64 x 32), 24 KB per LDS stage -> 3 workgroups per CU and twice the workgroups, so a 1,024-column
+// GEMM fills the chip in whole rounds.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_glds_n64_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W,
+                                                                 const void* __restrict__ bias, const bf16* resid,
+                                                                 void* Cout, int M, int N, int K, int ldc) {
+    __shared__ __attribute__((aligned(1024))) char lds[2][(64 + 128) * 128];   // [buf][W 64 rows | X 128 rows] x 128 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 128;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // staging: 24 pieces of 8 rows (W: 0..7, X: 8..23); this wave issues pieces wave*6 .. +5
+    const bf16* src[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int piece = wave * 6 + j;
+        const int row = piece * 8 + (lane >> 3);            // 0..63 = W rows, 64..191 = X rows
+        const int ch = (lane & 7) ^ (row & 7);
+        if (piece < 8) { int n = n0 + row; n = n < N ? n : N - 1; src[j] = W + (size_t)n * K + ch * 8; }
+        else { int m = m0 + row - 64; m = m < M ? m : M - 1; src[j] = X + (size_t)m * K + ch * 8; }
+    }
+    auto stage = [&](int kt, int buf) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            __builtin_amdgcn_global_load_lds(src[j] + kt * 64, (lds_void*)&lds[buf][(wave * 6 + j) * 1024], 16, 0, 0);
+    };
+    int aoff[4][2], boff[2][2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ra = i * 16 + fr;
+            aoff[i][hf] = ra * 128 + (((hf * 4 + fq) ^ (ra & 7)) << 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rb = 64 + wave * 32 + j * 16 + fr;    // (rb & 7) == ((rb - 64) & 7): the swizzle of the X row
+            boff[j][hf] = rb * 128 + (((hf * 4 + fq) ^ (rb & 7)) << 4);
+        }
+    }
+    const int nt = K / 64;
+    stage(0, 0);
+    for (int kt = 0; kt < nt; ++kt) {
+        const int buf = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nt) stage(kt + 1, buf ^ 1);
+        const char* Ls = lds[buf];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            bf16x8 a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Ls + aoff[i][hf]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(Ls + boff[j][hf]);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+    gemm_epilogue<bf16, EPI, 4, 2>(acc, n0, m0 + wave * 32, fr, fq, bias, resid, Cout, M, N, ldc);
+}
+
 static int gemm_glds_dispatch(const void* A, const void* W, const void* bias, const void* resid, void* C,
                               int M, int N, int K, int ldc, int epi, hipStream_t s) {
+    if (N <= 1024 && epi == VALLE_EPI_RESID) {      // narrow outputs: smaller tile, whole rounds of workgroups
+        dim3 g64(ceil_div(N, 64), ceil_div(M, 128));
+        gemm_glds_n64_bf16_kernel<VALLE_EPI_RESID><<<g64, 256, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
+        VALLE_LAUNCH_CHECK();
+        return VALLE_OK;
+    }
     dim3 grid(ceil_div(N, 128), ceil_div(M, 128));
 #define GLDS_CASE(E) case E: gemm_glds_bf16_kernel<E><<<grid, 256, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc); break;
     switch (epi) {
