@@ -112,7 +112,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm; VALLE_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs
+        # than ranks (ranks then share devices: local_rank % device_count)
+        dist.init_process_group(os.environ.get("VALLE_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+    local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -140,6 +143,7 @@ def main():
             raw = out.view(torch.uint8)                                 # RCCL has no int16: ship the bytes
             gathered = [torch.empty_like(raw) for _ in range(world)]
             dist.all_gather(gathered, raw)                              # RCCL: codes of every rank
+            assert all(g.shape == raw.shape for g in gathered)
         return out
 
     def fence():
