@@ -250,27 +250,61 @@ class AR_NAR(Base):
         prev = _host_codes(resps_list)
         sp = self.sample_params(**kw)
         null_text = [torch.tensor([1, 2]) for _ in range(B)]
-        for n in range(max_levels):
-            level = prev[0].shape[-1]
-            if level >= max_levels + 1:
-                break
-            R = [p.shape[0] for p in prev]
-            plan = self.plan(phns_list, lang_list, proms_list, prev, level)
-            rows, off = self.tail_rows(plan, R)
-            logits = self.forward_dense(plan, rows)
+        level0 = prev[0].shape[-1]
+        R = [p.shape[0] for p in prev]
+        total = int(sum(R))
+        levels = [q for q in range(level0, max_levels + 1)]
+        if not levels or total == 0:
+            return [torch.from_numpy(p).to(self.device) for p in prev]
+        # Every level's integer tables are planned on the host up front (the codes a level does not know yet are
+        # placeholders) and uploaded; the device then patches the response rows with the codes as they are
+        # sampled, so no level waits for a device->host copy and the GPU never idles between levels.
+        n_lv = self.n_resp_levels
+        off = np.concatenate(([0], np.cumsum(R))).astype(np.int32)
+        known = np.concatenate(prev).astype(np.int64)                                          # (total, level0)
+        ph = [np.concatenate([p, np.zeros((p.shape[0], n_lv - p.shape[1]), np.int64)], axis=1) for p in prev]
+        plans, nplans = {}, {}
+
+        def prepare(n):            # host planning of level n runs while the device is busy with level n - 1
+            if n >= len(levels):
+                return
+            q = levels[n]
+            resp_q = [x[:, :q] for x in ph]
+            plan = self.plan(phns_list, lang_list, proms_list, resp_q, q)
+            rows, _ = self.tail_rows(plan, R)
+            plans[n] = (plan, rows, self.upload_plan(plan, rows))
+            if cfg_strength > 0:
+                nplan = self.plan(null_text, lang_list, None, resp_q, q)
+                nrows, _ = self.tail_rows(nplan, R)
+                nplans[n] = (nplan, nrows, self.upload_plan(nplan, nrows))
+
+        prepare(0)
+        counts = np.diff(off)
+        row_item = np.repeat(np.arange(B, dtype=np.int32), counts)
+        row_in = np.concatenate([np.arange(c, dtype=np.int32) for c in counts])
+        ri, rn, poff, plen, known_d = self._upload_i32(row_item, row_in, off[:-1], counts, known)
+        base = torch.tensor([self._off[f"resp{l + 1}"] for l in range(n_lv - 1)], dtype=torch.int32, device=self.device)
+        resp_idx = torch.full((total, 8), -1, dtype=torch.int32, device=self.device)           # embedding rows of the codes so far
+        resp_idx[:, :level0] = known_d.view(total, level0) + base[None, :level0]
+        cols = [known_d.view(total, level0)[:, l].contiguous() for l in range(level0)]         # int32 codes per level
+        for n, q in enumerate(levels):
+            plan, rows, dev = plans.pop(n)
+            dev[0][dev[3].long(), :q] = resp_idx[:, :q]                                        # patch: sum of levels < q
+            logits = self.forward_dense(plan, rows, dev=dev)
+            prepare(n + 1)
             V = self.cls_tokens[plan.head]
             if cfg_strength > 0:
-                nplan = self.plan(null_text, lang_list, None, prev, level)
-                nrows, _ = self.tail_rows(nplan, R)
-                null = self.forward_dense(nplan, nrows)
+                nplan, nrows, ndev = nplans.pop(n)
+                ndev[0][ndev[3].long(), :q] = resp_idx[:, :q]
+                null = self.forward_dense(nplan, nrows, dev=ndev)
                 self.cfg_combine(logits, null, V, off, cfg_strength, cfg_rescale)
             sp.offset = 1000 + n
-            ids, _ = self.sample_rows(logits, V, off, prev, nar_mode=1, params=sp)
-            ids = ids.cpu().numpy().astype(np.int64)
-            prev = [np.concatenate([p, ids[off[i]:off[i + 1], None]], axis=-1) for i, p in enumerate(prev)]
-        flat = torch.from_numpy(np.concatenate(prev)).to(self.device)                # one upload, split into views
-        cuts = np.cumsum([0] + [p.shape[0] for p in prev])
-        return [flat[cuts[i]:cuts[i + 1]] for i in range(B)]
+            ids, _ = self.sample_rows(logits, V, off, None, nar_mode=1, params=sp, dev=(ri, rn, cols[-1], poff, plen))
+            cols.append(ids.contiguous())
+            if q < n_lv - 1:
+                resp_idx[:, q] = ids + base[q]
+        flat = torch.stack(cols, dim=1).long()                                                 # (total, levels) on the device
+        return [flat[off[i]:off[i + 1]] for i in range(B)]
 
     # ------------------------------------------------------------------------------- NAR-len
     def forward_nar_masked(self, task_list=None, phns_list=None, proms_list=None, resps_list=None, lang_list=None,

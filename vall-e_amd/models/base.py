@@ -305,15 +305,32 @@ class Base:
     def _i32(self, arr):
         return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)).to(self.device, non_blocking=True)
 
-    def forward_dense(self, plan: Plan, out_rows, *, cache=None, want_hidden=False):
+    def _upload_i32(self, *arrays):
+        """Several integer host arrays -> device int32 views of ONE uploaded buffer (one copy, one sync)."""
+        flat = [np.ascontiguousarray(a, dtype=np.int32).reshape(-1) for a in arrays]
+        pad = [(-len(f)) % 4 for f in flat]                                   # keep every view 16-byte aligned
+        buf = np.concatenate([np.concatenate((f, np.zeros(p, np.int32))) for f, p in zip(flat, pad)]) if flat else np.zeros(0, np.int32)
+        dev = torch.from_numpy(buf).to(self.device, non_blocking=True)
+        out, o = [], 0
+        for a, f, p in zip(arrays, flat, pad):
+            out.append(dev[o:o + len(f)].view(np.asarray(a).shape))
+            o += len(f) + p
+        return out
+
+    def upload_plan(self, plan: Plan, out_rows):
+        """Device copies of a plan's integer tables: (idx [M][8], pos [M], cu [B+1], rows [n_out])."""
+        return tuple(self._upload_i32(plan.idx, plan.pos, plan.cu, out_rows))
+
+    def forward_dense(self, plan: Plan, out_rows, *, cache=None, want_hidden=False, dev=None):
         """Runs the stack on a packed plan; returns fp32 logits (n_out, ld) for the packed row ids
-        in ``out_rows`` (head = plan.head).  cache = (k, v, cache_T, layer_stride, slot, pos0)."""
+        in ``out_rows`` (head = plan.head).  cache = (k, v, cache_T, layer_stride, slot, pos0);
+        dev = upload_plan(...) made earlier (possibly patched on the device since)."""
         self._prepare()
         lib = L.load()
         n_out = int(len(out_rows))
         vocab = self.cls_tokens[plan.head]
         ld = _round_up(vocab, 8)
-        idx, pos, cu, rows = self._i32(plan.idx), self._i32(plan.pos), self._i32(plan.cu), self._i32(out_rows)
+        idx, pos, cu, rows = dev if dev is not None else self.upload_plan(plan, out_rows)
         logits = torch.empty((n_out, ld), dtype=torch.float32, device=self.device)
         hidden = torch.empty((n_out, self.d_model), dtype=self.dtype, device=self.device) if want_hidden else None
         need = lib.valle_dense_workspace_bytes(self._handle, plan.M, n_out)
@@ -361,11 +378,20 @@ class Base:
                               float(repetition_penalty), float(repetition_penalty_decay), float(length_penalty),
                               int(self.stop_token), int(rep_pen_passes), int(seed), int(offset))
 
-    def sample_rows(self, logits, vocab, row_off, prev_list, nar_mode, params):
-        """valle_sample over packed logits rows; row_off = per-utterance row offsets (B+1)."""
+    def sample_rows(self, logits, vocab, row_off, prev_list, nar_mode, params, dev=None):
+        """valle_sample over packed logits rows; row_off = per-utterance row offsets (B+1).
+        dev = (row_item, row_in_item, prev, prev_off, prev_len) already on the device."""
         lib = L.load()
         B = len(row_off) - 1
         rows = int(row_off[-1])
+        if dev is not None:
+            ri, rn, prev, prev_off, prev_len = dev
+            ids = torch.empty(max(rows, 1), dtype=torch.int32, device=self.device)
+            scores = torch.empty(max(rows, 1), dtype=torch.float32, device=self.device)
+            L.check(lib.valle_sample(L.ptr(logits), logits.shape[1], vocab, rows, L.ptr(ri), L.ptr(rn), L.ptr(prev),
+                                     L.ptr(prev_off), L.ptr(prev_len), int(nar_mode), C.byref(params), L.ptr(ids), L.ptr(scores),
+                                     L.stream_ptr(self.device)))
+            return ids[:rows], scores[:rows]
         counts = np.diff(row_off)
         row_item = np.repeat(np.arange(B, dtype=np.int32), counts)
         row_in = np.concatenate([np.arange(c, dtype=np.int32) for c in counts]) if rows else np.zeros(0, np.int32)
