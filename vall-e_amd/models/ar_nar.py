@@ -342,6 +342,22 @@ class AR_NAR(Base):
         null_text = [torch.tensor([1, 2]) for _ in range(B)]
         V = self.cls_tokens[self.cls_names.index("NAR:0:0")]
         stream = L.stream_ptr(dev)
+        # the sequence layout does not change between demasking steps: both plans are built and uploaded once, and
+        # every step patches the response rows' embedding ids with the current codes on the device
+        zeros = [np.zeros(n, np.int64) for n in lens]
+        plan = self.plan(phns_list, lang_list, proms_list, zeros, 0, timestep=True)
+        rows, roff = self.tail_rows(plan, lens)
+        pdev = self.upload_plan(plan, rows)
+        prow = pdev[3].long()
+        resp_base = self._off[f"resp{self.emb_names.index('NAR:0:0')}"]
+        if cfg_strength > 0:
+            nplan = self.plan(null_text, lang_list, None, zeros, 0, timestep=True)
+            nrows, _ = self.tail_rows(nplan, lens)
+            ndev = self.upload_plan(nplan, nrows)
+            nrow = ndev[3].long()
+        counts = np.diff(roff)
+        ri, rn, poff, plen = self._upload_i32(np.repeat(np.arange(B, dtype=np.int32), counts),
+                                              np.concatenate([np.arange(c, dtype=np.int32) for c in counts]), roff[:-1], counts)
         for step, t in enumerate(torch.linspace(start_noise, end_noise, max_steps)):
             noise_p = math.cos(t * math.pi * 0.5)                               # float32 timestep, as the reference
             mask_p = noise_p + (1.0 / (max_steps * 2) if remasking else 0)
@@ -350,24 +366,20 @@ class AR_NAR(Base):
             L.check(lib.valle_mask_lowest(L.ptr(scores), L.ptr(codes), L.ptr(is_masked), L.ptr(off_d), L.ptr(ks), B,
                                           max(lens), self.mask_token, stream))
             temp = temperature * (1.0 - float(t)) if annealed else temperature
-            codes_h = codes.cpu().numpy()
-            resps = [codes_h[off[i]:off[i + 1]] for i in range(B)]
-            plan = self.plan(phns_list, lang_list, proms_list, resps, 0, timestep=True)
-            rows, roff = self.tail_rows(plan, lens)
-            logits = self.forward_dense(plan, rows)
+            pdev[0][prow, 0] = codes + resp_base
+            logits = self.forward_dense(plan, rows, dev=pdev)
             if cfg_strength > 0:
-                nplan = self.plan(null_text, lang_list, None, resps, 0, timestep=True)
-                nrows, _ = self.tail_rows(nplan, lens)
-                null = self.forward_dense(nplan, nrows)
+                ndev[0][nrow, 0] = codes + resp_base
+                null = self.forward_dense(nplan, nrows, dev=ndev)
                 self.cfg_combine(logits, null, V, roff, cfg_strength, cfg_rescale)
-            prev = [prev_codes[off[i]:off[i + 1]] for i in range(B)]
+            sdev = (ri, rn, prev_codes, poff, plen)
             sp1 = self.sample_params(temperature=temp, **kw)
             sp1.offset = 2000 + step
-            ids, _ = self.sample_rows(logits, V, roff, prev, nar_mode=1, params=sp1)
+            ids, _ = self.sample_rows(logits, V, roff, None, nar_mode=1, params=sp1, dev=sdev)
             # the reference's second ("unfiltered") sample runs on tensors its in-place processors
             # have already touched: the repetition penalty is applied a second time
             sp2 = self.sample_params(temperature=0.0, rep_pen_passes=2 if kw.get("repetition_penalty", 1.0) != 1.0 else 1, **kw)
-            _, sc = self.sample_rows(logits, V, roff, prev, nar_mode=1, params=sp2)
+            _, sc = self.sample_rows(logits, V, roff, None, nar_mode=1, params=sp2, dev=sdev)
             codes = torch.where(is_masked.bool(), ids, codes)                  # ar_nar.py:457
             scores = sc                                                        # ar_nar.py:462
         codes = codes.to(torch.int16)
