@@ -418,3 +418,36 @@ def test_narlen_b64_properties(gpu_device):
     solo = m(task_list=["tts"], phns_list=phns[5:6], proms_list=proms[5:6], lang_list=langs[5:6], len_list=[R], **kw)
     agree = (solo[0] == out[5]).float().mean().item()
     assert agree > 0.9, agree          # bf16 GEMM tiles see different neighbours; greedy near-ties may flip a few codes
+
+
+@pytest.mark.parametrize("cache_T,ctx", [(96, [1, 7, 96]), (512, [512, 65, 300]), (1024, [1000, 3, 769, 768]), (2600, [2561, 1537, 40])])
+def test_attn_decode_bf16_vs_fp64(gpu_device, cache_T, ctx):
+    """valle_attn_decode (bf16 KV-cache attention, one query per utterance and head) against an fp64
+    softmax(q.K^T/8) V over the first ctx_b rows of each utterance's slot: ragged contexts, single- and
+    multi-pass key ranges, waves without keys, a permuted slot table; garbage beyond ctx_b must not leak."""
+    from vall_e_amd import _lib as L
+    B, H, Dh = len(ctx), 4, 64
+    d = H * Dh
+    g = torch.Generator().manual_seed(cache_T + B)
+    qkv = torch.randn(B, 3 * d, generator=g).bfloat16()
+    kc = torch.randn(B, H, cache_T, Dh, generator=g).bfloat16()
+    vc = torch.randn(B, H, cache_T, Dh, generator=g).bfloat16()
+    slot = torch.randperm(B, generator=g).int()
+    for b in range(B):                                    # poison what lies beyond the context
+        kc[slot[b], :, ctx[b]:] = float("nan")
+        vc[slot[b], :, ctx[b]:] = float("inf")
+    want = torch.empty(B, d, dtype=torch.float64)
+    for b in range(B):
+        q = qkv[b, :d].double().view(H, 1, Dh)
+        K = kc[slot[b], :, : ctx[b]].double()
+        V = vc[slot[b], :, : ctx[b]].double()
+        p = torch.softmax(q @ K.transpose(1, 2) / 8.0, dim=-1)
+        want[b] = (p @ V).reshape(d)
+    out = torch.zeros(B, d, dtype=torch.bfloat16, device=gpu_device)
+    qd, kd, vd = qkv.to(gpu_device), kc.to(gpu_device), vc.to(gpu_device)
+    cl, sl = torch.tensor(ctx, dtype=torch.int32, device=gpu_device), slot.to(gpu_device)
+    L.check(L.load().valle_attn_decode(L.ptr(qd), L.ptr(kd), L.ptr(vd), L.ptr(cl), L.ptr(sl), L.ptr(out), B, H, Dh, cache_T,
+                                       L.BF16, L.stream_ptr()))
+    got = out.double().cpu()
+    assert torch.isfinite(got).all()
+    assert ((got - want).norm() / want.norm()).item() < 1e-2
