@@ -158,28 +158,25 @@ typedef struct {
 
 typedef struct {
     const void *ln1, *w_qkv, *w_o, *ln2, *w_gu, *w_down;
-    /* bf16 decode copies in streaming order (may be NULL for VALLE_F32): the same matrices tiled as
-     * [N/16][K/64][2][64 lanes][8]: lane l = fq*16 + fr of tile (nt, ks, half) holds
-     * W[nt*16 + fr][ks*64 + half*32 + fq*8 .. +8], i.e. exactly the MFMA A fragment, so one
-     * wave-instruction reads 1 KiB of contiguous memory and a workgroup's whole slice is contiguous. */
-    const void *p_qkv, *p_o, *p_gu, *p_down;
-    /* streaming-order copies of w_qkv and w_gu with the preceding RMSNorm weight multiplied in
-     * (W[n][k] * ln[k], rounded to bf16 once): the <= 16-utterance decode kernels apply 1/rms(x) to the
-     * accumulator instead of normalising x first.  May be NULL (then the p_* path is used). */
-    const void *pn_qkv, *pn_gu;
+    /* bf16 decode copies in streaming order (may be NULL; required for the fast VALLE_BF16 decode path): the same
+     * matrices tiled as [N/16][K/64][2][64 lanes][8]: lane l = fq*16 + fr of tile (nt, ks, half) holds
+     * W[nt*16 + fr][ks*64 + half*32 + fq*8 .. +8], i.e. exactly the MFMA A fragment, so one wave-instruction
+     * reads 1 KiB of contiguous memory and a wave's whole slice is contiguous.
+     * pn_qkv / pn_gu: w_qkv / w_gu with the preceding RMSNorm weight multiplied in (W[n][k] * ln[k], rounded to
+     * bf16 once): the decode kernels apply 1/rms(x) to the accumulator instead of normalising x first. */
+    const void *p_o, *p_down, *pn_qkv, *pn_gu;
 } valle_layer_weights;
 
 typedef struct valle_model valle_model;
 
 /* Builds a host-side descriptor holding the device pointers (no device allocation, no copy).
  * heads: n_cls classifier heads (models/base.py:179-231), head k = (w [n_k][d], b [n_k] fp32 or NULL);
- * head_p_host: optional streaming-order copies of the head weights (rows padded to a multiple of 16);
- * head_pn_host: the same with the final norm weight multiplied in (see valle_layer_weights.pn_*). */
+ * head_pn_host: optional streaming-order copies of the head weights (rows padded to a multiple of 16) with the
+ * final norm weight multiplied in (see valle_layer_weights.pn_*). */
 int valle_model_create(const valle_config* cfg, const void* emb, const float* rope,
                        const valle_layer_weights* layers_host, const void* final_norm,
                        int n_cls, const void* const* head_w_host, const float* const* head_b_host,
-                       const int32_t* head_n_host, const void* const* head_p_host,
-                       const void* const* head_pn_host, valle_model** out);
+                       const int32_t* head_n_host, const void* const* head_pn_host, valle_model** out);
 void valle_model_destroy(valle_model* m);
 
 /* Workspace bytes valle_forward_dense needs for M packed rows and n_out output rows. */

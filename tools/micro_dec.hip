@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 16;
     const int ctx = argc > 2 ? atoi(argv[2]) : 536;
     const int CT = 768;
-    const int dbg = argc > 3 ? atoi(argv[3]) : 0;
+    (void)(argc > 3 ? atoi(argv[3]) : 0);                       // (argv[3] kept for old command lines)
     const bool force_eager = argc > 4 && atoi(argv[4]) != 0;   // counter runs: one dispatch record per kernel
     std::vector<bf16*> wqkv(L), wo(L), wgu(L), wdn(L), kc(L), vc(L);
     const size_t per = (size_t)B * H * CT * 64;
@@ -67,23 +67,14 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&x, 32 * d * 2)); CK(hipMalloc(&att, 32 * d * 2)); CK(hipMalloc(&ff, 32 * f * 2)); CK(hipMalloc(&nw, d * 2));
     CK(hipMalloc(&qkv, B * 3 * d * 2)); CK(hipMalloc(&rope, 1024 * 64 * 4)); CK(hipMalloc(&pos, B * 4)); CK(hipMalloc(&ctxl, B * 4));
     CK(hipMalloc(&sink, 1 << 20));
-    float* ssq; CK(hipMalloc(&ssq, 16 * 256 * 4)); CK(hipMemset(ssq, 0, 16 * 256 * 4));
-    FILL(x, 16 * d * 2, 1); FILL(att, 16 * d * 2, 2); FILL(ff, 16 * f * 2, 3); FILL(nw, d * 2, 4);
+    float* ssq; CK(hipMalloc(&ssq, 32 * 256 * 4)); CK(hipMemset(ssq, 0, 32 * 256 * 4));
+    FILL(x, 32 * d * 2, 1); FILL(att, 32 * d * 2, 2); FILL(ff, 32 * f * 2, 3); FILL(nw, d * 2, 4);
     FILL(qkv, B * 3 * d * 2, 5); CK(hipDeviceSynchronize()); CK(hipMemset(rope, 0, 1024 * 64 * 4)); CK(hipMemset(pos, 0, B * 4));
     { std::vector<int32_t> hc(B, ctx); CK(hipMemcpy(ctxl, hc.data(), B * 4, hipMemcpyHostToDevice)); }
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = force_eager ? 2 : 20;
 
-    auto mk = [&](const bf16* xx, const bf16* norm, const bf16* W, const bf16* resid, void* out, int ldo, int N, int K) {
-        DecArgs a{}; a.x = xx; a.norm_w = norm; a.eps = 1e-6f; a.W = W; a.resid = resid; a.out = out; a.ldo = ldo; a.B = B; a.N = N; a.K = K; a.dbg = dbg; return a; };
-    auto k_qkv = [&](int l) { DecArgs a = mk(x, nw, wqkv[l], nullptr, qkv, 3 * d, 3 * d, d);
-        a.rope = rope; a.pos = pos; a.ctx_len = ctxl; a.slot = nullptr; a.kc = kc[l]; a.vc = vc[l]; a.cache_T = CT; a.H = H; a.d = d;
-        return valle_dec_linear_bf16(a, DEC_EPI_QKV, s); };
-    auto k_attn = [&](int l) { return valle_attn_decode_launch(qkv, kc[l], vc[l], ctxl, nullptr, att, B, H, 64, CT, 1, VALLE_BF16, s); };
-    auto k_o = [&](int l) { return valle_dec_linear_bf16(mk(att, nullptr, wo[l], x, x, d, d, d), VALLE_EPI_RESID, s); };
-    auto k_gu = [&](int l) { return valle_dec_linear_bf16(mk(x, nw, wgu[l], nullptr, ff, f, 2 * f, d), VALLE_EPI_GEGLU, s); };
-    auto k_dn = [&](int l) { return valle_dec_linear_bf16(mk(ff, nullptr, wdn[l], x, x, d, d, f), VALLE_EPI_RESID, s); };
     auto mkw = [&](const bf16* xx, int norm, const bf16* W, const bf16* resid, void* out, int ldo, int N, int K) {
         DecWArgs a{}; a.x = xx; a.norm = norm; a.eps = 1e-6f; a.W = W; a.resid = resid; a.out = out; a.ldo = ldo; a.B = B; a.N = N; a.K = K; a.ssq_in = ssq; a.ssq_out = resid ? ssq : nullptr; return a; };
     auto w_qkv = [&](int l) { DecWArgs a = mkw(x, 1, wqkv[l], nullptr, qkv, 3 * d, 3 * d, d);
@@ -94,7 +85,6 @@ int main(int argc, char** argv) {
     auto w_dn = [&](int l) { return valle_dec_wave_linear(mkw(ff, 0, wdn[l], x, x, d, d, f), VALLE_EPI_RESID, s); };
     auto w_attn = [&](int l) { return valle_attn_decode_bf16(qkv, 3 * d, kc[l], vc[l], ctxl, nullptr, att, B, H, CT, 1, 1, s); };
     auto wlayer = [&](int l) { int rc = w_qkv(l); rc |= w_attn(l); rc |= w_o(l); rc |= w_gu(l); rc |= w_dn(l); return rc; };
-    auto layer = [&](int l) { int rc = k_qkv(l); rc |= k_attn(l); rc |= k_o(l); rc |= k_gu(l); rc |= k_dn(l); return rc; };
 
     // times `fn(l)` for l in 0..L-1 as one dependent chain; graph = captured once, replayed
     auto timeit = [&](const char* name, double mb, bool graph, auto fn) -> int {
@@ -138,12 +128,7 @@ int main(int argc, char** argv) {
         if (timeit("stream 25MB (512 blk x 48KB, 256thr)", 25.2, true, [&](int l) { stream2_kernel<49152, 256><<<512, 256, 0, s>>>((const uint4*)kc[l], sink, (size_t)49152 / 16); return 0; })) return 1;
         if (timeit("stream 25MB (1024 blk x 24KB, 256thr)", 25.2, true, [&](int l) { stream2_kernel<24576, 256><<<1024, 256, 0, s>>>((const uint4*)kc[l], sink, (size_t)24576 / 16); return 0; })) return 1;
     }
-    if (timeit("dec qkv+rope+append", mb_qkv, true, k_qkv)) return 1;
-    if (timeit("dec attention", mb_att, true, k_attn)) return 1;
-    if (timeit("dec o_proj", mb_o, true, k_o)) return 1;
-    if (timeit("dec gate/up GEGLU", mb_gu, true, k_gu)) return 1;
-    if (timeit("dec down", mb_dn, true, k_dn)) return 1;
-    if (B <= 16) {
+    {
         if (timeit("wave qkv+rope+append", mb_qkv, true, w_qkv)) return 1;
         if (timeit("wave attention", mb_att, true, w_attn)) return 1;
         if (timeit("wave o_proj", mb_o, true, w_o)) return 1;
@@ -151,9 +136,8 @@ int main(int argc, char** argv) {
         if (timeit("wave down", mb_dn, true, w_dn)) return 1;
     }
     const double mb_layer = mb_qkv + mb_o + mb_gu + mb_dn + mb_att;
-    if (timeit("LAYER (5 kernels)", mb_layer, false, layer)) return 1;
-    if (timeit("LAYER (5 kernels)", mb_layer, true, layer)) return 1;
-    if (B <= 16 && timeit("WAVE LAYER (5 kernels)", mb_layer, true, wlayer)) return 1;
+    if (timeit("WAVE LAYER (5 kernels)", mb_layer, false, wlayer)) return 1;
+    if (timeit("WAVE LAYER (5 kernels)", mb_layer, true, wlayer)) return 1;
     printf("last error: %s\n", valle_last_error());
     return 0;
 }

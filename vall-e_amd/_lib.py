@@ -36,8 +36,7 @@ class Config(C.Structure):
 
 
 class LayerWeights(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("ln1", "w_qkv", "w_o", "ln2", "w_gu", "w_down", "p_qkv", "p_o", "p_gu", "p_down",
-                                            "pn_qkv", "pn_gu")]
+    _fields_ = [(n, C.c_void_p) for n in ("ln1", "w_qkv", "w_o", "ln2", "w_gu", "w_down", "p_o", "p_down", "pn_qkv", "pn_gu")]
 
 
 class ARState(C.Structure):
@@ -67,8 +66,7 @@ SIGNATURES = {
     "valle_cfg_combine": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_float, c_float, c_void_p]),
     "valle_mask_lowest": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "valle_model_create": (c_int, [C.POINTER(Config), c_void_p, c_void_p, C.POINTER(LayerWeights), c_void_p, c_int,
-                                   C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(C.c_int32), C.POINTER(c_void_p), C.POINTER(c_void_p),
-                                   C.POINTER(c_void_p)]),
+                                   C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(C.c_int32), C.POINTER(c_void_p), C.POINTER(c_void_p)]),
     "valle_model_destroy": (None, [c_void_p]),
     "valle_dense_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "valle_forward_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnDecArgs a
             den += sm_l[w] * sc;
         }
         const int col = h * 64 + threadIdx.x;
-        const size_t off = a.out_frag ? (size_t)(((((col >> 5) << 6) + (((col >> 3) & 3) << 4) + b) << 3) + (col & 7))
+        const size_t off = a.out_frag ? (size_t)(b >> 4) * 16 * a.H * 64 + (size_t)(((((col >> 5) << 6) + (((col >> 3) & 3) << 4) + (b & 15)) << 3) + (col & 7))
                                       : (size_t)b * a.H * 64 + col;
         a.out[off] = (bf16)(num / den);
     }
@@ -135,7 +135,6 @@ int valle_attn_decode_bf16(const void* q, size_t q_row_stride, const void* kcach
                            const int32_t* ctx_len, const int32_t* cache_slot, void* out, int B, int H, int cache_T,
                            int ctx_extra, int out_frag, hipStream_t s) {
     VALLE_REQUIRE(q && kcache && vcache && ctx_len && out, VALLE_E_ARG, "valle_attn_decode: null pointer");
-    VALLE_REQUIRE(!out_frag || B <= 16, VALLE_E_ARG, "valle_attn_decode: fragment-order output holds 16 utterances");
     if (B == 0) return VALLE_OK;
     AttnDecArgs a{};
     a.q = (const bf16*)q; a.q_row_stride = q_row_stride; a.k = (const bf16*)kcache; a.v = (const bf16*)vcache;

@@ -75,7 +75,6 @@ struct valle_model {
     int n_cls;
     const void** head_w;
     const float** head_b;
-    const void** head_p;
     const void** head_pn;
     int32_t* head_n;
 };
@@ -97,20 +96,7 @@ struct SampleArgs {
 };
 int valle_sample_launch(const SampleArgs& a, int rows, hipStream_t s);
 
-// decode-path launcher (gemm.hip)
 #define DEC_EPI_QKV 10
-struct DecArgs {
-    const bf16* x; const bf16* norm_w; float eps;
-    const bf16* W; const float* bias; const bf16* resid;
-    void* out; int ldo;
-    int B, N, K;
-    // QKV epilogue: RoPE + KV-cache append
-    const float* rope; const int32_t* pos; const int32_t* ctx_len; const int32_t* slot;
-    bf16* kc; bf16* vc; int cache_T; int H; int d;
-    int dbg;   // dev ablation switches (0 in production)
-};
-int valle_dec_linear_bf16(const DecArgs& a, int epilogue, hipStream_t s);
-
 // wave-streaming decode linears (dec_linear.hip): activations in fragment order, norm weight folded into W
 struct DecWArgs {
     const bf16* x; const bf16* W; const float* bias; const bf16* resid;

@@ -1,6 +1,6 @@
 // MFMA GEMMs of the AR+NAR forward (gfx950).
 //   valle_gemm        dense passes (prefill, NAR levels, NAR-len steps): C = A . W^T, epilogues
-//   valle_dec_linear  AR decode step, B <= 32 rows: weight-streaming, RMSNorm prologue fused
+// (the AR decode step's linears are in dec_linear.hip)
 // nn.Linear call sites replaced: models/arch/llama.py:307-309 (q/k/v), :475 (o_proj),
 // :492 (gate/up/down), models/base.py:217 (classifier heads).
 //
@@ -357,207 +357,4 @@ extern "C" int valle_gemm(const void* A, const void* W, const void* bias, const 
     if (dtype == VALLE_F32) return gemm_dispatch<float>(A, W, bias, resid, C, M, N, K, ldc, epilogue, s);
     valle_set_error("valle_gemm: unknown dtype %d", dtype);
     return VALLE_E_ARG;
-}
-
-// ===================================================================== decode linears
-// out[B<=32][N] = f(rmsnorm?(x)[B][K] . W[N][K]^T): one workgroup per 16 weight rows, the 4
-// waves split K; every lane's weight loads are issued before anything else (the stream is
-// read exactly once, straight to VGPRs), the RMSNorm of the <=32 activation rows is recomputed
-// per workgroup from L2 while they fly.  k-slot permutation: a lane reads 32 contiguous bytes
-// of its weight row per MFMA pair (elements kb+16g+{0..7} feed MFMA 0, +{8..15} MFMA 1) and
-// the activation fragment uses the same permutation, so the sum over k is unchanged.
-
-template <int EPI, bool NORM, int MT, int STEPS, int NW>
-__global__ __launch_bounds__(NW * 64) void dec_linear_kernel(DecArgs a) {
-    constexpr int NT = NW * 64;
-    constexpr int KW = STEPS * 64;          // k range of one wave
-    constexpr int K = KW * NW;
-    constexpr int XS = K + 8;               // LDS row stride (elements): +16 B shifts banks per row
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    const int kb0 = wave * KW;
-    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
-    float* s_part = reinterpret_cast<float*>(dyn_lds);                       // [NW][MT][16][17]
-    float* s_ss = s_part + NW * MT * 16 * 17;                                // [32]
-    bf16* xs = reinterpret_cast<bf16*>(s_ss + 32);                           // NORM: [MT*16][XS]
-
-    // ---- 1. activation loads are issued FIRST: vector-memory results return in issue order, so
-    // the (L2-resident) activations land while the weight stream is still in flight
-    constexpr int CPR = K / 8;                           // 16-B chunks per row
-    constexpr int NCH = NORM ? MT * 16 * CPR / NT : 1;   // chunks per thread
-    constexpr int RED = CPR >= 64 ? 64 : CPR;            // lanes that share a row
-    bf16x8 xc[NCH], gc[NCH];
-    bf16x8 x0[NORM ? 1 : STEPS][MT], x1[NORM ? 1 : STEPS][MT];
-    if constexpr (NORM) {
-        if (tid < 32) s_ss[tid] = 0.f;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + NT * i, row = c / CPR, col = (c % CPR) * 8;
-            xc[i] = *reinterpret_cast<const bf16x8*>(a.x + (size_t)(row < a.B ? row : a.B - 1) * K + col);
-            gc[i] = *reinterpret_cast<const bf16x8*>(a.norm_w + col);
-        }
-    } else {
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s)
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const int m = t * 16 + fr;
-                const bf16* xp = a.x + (size_t)(m < a.B ? m : a.B - 1) * K + kb0 + s * 64 + fq * 8;
-                x0[s][t] = *reinterpret_cast<const bf16x8*>(xp);
-                x1[s][t] = *reinterpret_cast<const bf16x8*>(xp + 32);
-            }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- 1b. the weight stream: W is pre-tiled [N/16][K/64][2][64][8] (valle_hip.h), so this wave's
-    // slice is 2*STEPS KiB of contiguous memory read 1 KiB per instruction
-    const bf16* wt = a.W + ((size_t)blockIdx.x * (K / 64) + wave * STEPS) * 1024 + lane * 8;
-    bf16x8 w0[STEPS], w1[STEPS];
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-        w0[s] = *reinterpret_cast<const bf16x8*>(wt + s * 1024);
-        w1[s] = *reinterpret_cast<const bf16x8*>(wt + s * 1024 + 512);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- 2. activation operand
-    if constexpr (NORM) {
-        // all threads: sum of squares per row (atomics in LDS), normalise, -> LDS
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + NT * i, row = c / CPR;
-            float ss = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float f = (float)xc[i][e]; ss += f * f; }
-#pragma unroll
-            for (int o = RED / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-            if ((lane & (RED - 1)) == 0) atomicAdd(&s_ss[row], ss);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = tid + NT * i, row = c / CPR, col = (c % CPR) * 8;
-            const float ri = __builtin_amdgcn_rsqf(s_ss[row] * (1.0f / (float)K) + a.eps);
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)gc[i][e] * (float)(bf16)((float)xc[i][e] * ri));
-            *reinterpret_cast<bf16x8*>(xs + row * XS + col) = o;
-        }
-        __syncthreads();
-    }
-    // ---- 3. MFMAs (rows m >= B produce garbage columns that are never stored)
-    f32x4 acc[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            bf16x8 b0, b1;
-            if constexpr (NORM) {
-                const bf16* xp = xs + (t * 16 + fr) * XS + kb0 + s * 64 + fq * 8;
-                b0 = *reinterpret_cast<const bf16x8*>(xp);
-                b1 = *reinterpret_cast<const bf16x8*>(xp + 32);
-            } else {
-                b0 = x0[s][t]; b1 = x1[s][t];
-            }
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[s], b0, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[s], b1, acc[t], 0, 0, 0);
-        }
-    }
-    // ---- 4. cross-wave reduction through LDS
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s_part[((wave * MT + t) * 16 + fq * 4 + r) * 17 + fr] = acc[t][r];
-    __syncthreads();
-    // thread -> (m, pair of n): 16*MT rows x 8 pairs
-    for (int idx = tid; idx < 16 * MT * 8; idx += NT) {
-        const int m = idx & (16 * MT - 1), np = idx / (16 * MT);
-        if (m >= a.B) continue;
-        const int t = m >> 4, mm = m & 15;
-        float v0 = 0.f, v1 = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            v0 += s_part[((w * MT + t) * 16 + 2 * np) * 17 + mm];
-            v1 += s_part[((w * MT + t) * 16 + 2 * np + 1) * 17 + mm];
-        }
-        const int n = n0 + 2 * np;
-        if (n >= a.N) continue;
-        if constexpr (EPI == VALLE_EPI_F32OUT) {
-            float* o = (float*)a.out + (size_t)m * a.ldo;
-            o[n] = v0 + (a.bias ? a.bias[n] : 0.f);
-            if (n + 1 < a.N) o[n + 1] = v1 + (a.bias ? a.bias[n + 1] : 0.f);
-        } else if constexpr (EPI == VALLE_EPI_RESID) {
-            bf16* o = (bf16*)a.out + (size_t)m * a.ldo;
-            const bf16* rs = a.resid + (size_t)m * a.ldo;
-            bf16x2 ov;
-            ov[0] = (bf16)((float)rs[n] + (float)(bf16)v0);
-            ov[1] = (bf16)((float)rs[n + 1] + (float)(bf16)v1);
-            *reinterpret_cast<bf16x2*>(o + n) = ov;
-        } else if constexpr (EPI == VALLE_EPI_GEGLU) {
-            bf16* o = (bf16*)a.out + (size_t)m * a.ldo;
-            o[n >> 1] = (bf16)((float)(bf16)gelu_erf((float)(bf16)v0) * (float)(bf16)v1);
-        } else if constexpr (EPI == DEC_EPI_QKV) {
-            const int d = a.d;
-            const int which = n / d, c = n - which * d, h = c >> 6, e = c & 63;
-            bf16 o0 = (bf16)v0, o1 = (bf16)v1;
-            if (which < 2) {
-                const float* tab = a.rope + (size_t)a.pos[m] * 64 + (e >> 1) * 2;
-                const float cs = (float)(bf16)tab[0], sn = (float)(bf16)tab[1];
-                const float x0f = (float)o0, x1f = (float)o1;
-                o0 = (bf16)(__fadd_rn(__fmul_rn(x0f, cs), __fmul_rn(-x1f, sn)));
-                o1 = (bf16)(__fadd_rn(__fmul_rn(x1f, cs), __fmul_rn(x0f, sn)));
-            }
-            bf16x2 ov; ov[0] = o0; ov[1] = o1;
-            if (which == 0) {
-                *reinterpret_cast<bf16x2*>((bf16*)a.out + (size_t)m * a.ldo + n) = ov;
-            } else {
-                const int sl = a.slot ? a.slot[m] : m;
-                bf16* cp = (which == 1 ? a.kc : a.vc) + (((size_t)sl * a.H + h) * a.cache_T + a.ctx_len[m]) * 64 + e;
-                *reinterpret_cast<bf16x2*>(cp) = ov;
-            }
-        }
-    }
-}
-
-template <int EPI, bool NORM, int STEPS, int NW>
-static int dec_launch2(const DecArgs& a, hipStream_t s) {
-    const int grid = ceil_div(a.N, 16);
-    constexpr int K = STEPS * 64 * NW;
-    auto lds = [&](int MT) { return (size_t)(NW * MT * 16 * 17 + 32) * 4 + (NORM ? (size_t)MT * 16 * (K + 8) * 2 : 0); };
-    if (a.B <= 16) dec_linear_kernel<EPI, NORM, 1, STEPS, NW><<<grid, NW * 64, lds(1), s>>>(a);
-    else {
-        static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-        if (!attr_set && lds(2) > 65536) {
-            VALLE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_linear_kernel<EPI, NORM, 2, STEPS, NW>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(2)));
-            attr_set = true;
-        }
-        dec_linear_kernel<EPI, NORM, 2, STEPS, NW><<<grid, NW * 64, lds(2), s>>>(a);
-    }
-    VALLE_LAUNCH_CHECK();
-    return VALLE_OK;
-}
-
-// bf16 only.  RMSNorm-prologue linears (QKV, gate/up, heads) take K = d_model in {256, 1024};
-// residual linears (o_proj, down_proj) K in {256, 1024, 4096}.
-int valle_dec_linear_bf16(const DecArgs& a, int epilogue, hipStream_t s) {
-    VALLE_REQUIRE(a.B >= 1 && a.B <= 32, VALLE_E_UNSUPPORTED, "decode linears are built for 1..32 utterances per step, got %d", a.B);
-    VALLE_REQUIRE(a.N % 2 == 0 || epilogue == VALLE_EPI_F32OUT, VALLE_E_ARG, "decode linear: odd N needs the fp32 epilogue");
-    const bool norm = a.norm_w != nullptr;
-    const int K = a.K;
-    if (norm && (K == 256 || K == 1024)) {
-        switch (epilogue) {
-            case VALLE_EPI_GEGLU:  return K == 256 ? dec_launch2<VALLE_EPI_GEGLU, true, 1, 4>(a, s) : dec_launch2<VALLE_EPI_GEGLU, true, 4, 4>(a, s);
-            case VALLE_EPI_F32OUT: return K == 256 ? dec_launch2<VALLE_EPI_F32OUT, true, 1, 4>(a, s) : dec_launch2<VALLE_EPI_F32OUT, true, 4, 4>(a, s);
-            case DEC_EPI_QKV:      return K == 256 ? dec_launch2<DEC_EPI_QKV, true, 1, 4>(a, s) : dec_launch2<DEC_EPI_QKV, true, 4, 4>(a, s);
-        }
-    } else if (!norm && epilogue == VALLE_EPI_RESID) {
-        if (K == 256) return dec_launch2<VALLE_EPI_RESID, false, 1, 4>(a, s);
-        if (K == 1024) return dec_launch2<VALLE_EPI_RESID, false, 2, 8>(a, s);
-        if (K == 4096) return dec_launch2<VALLE_EPI_RESID, false, 8, 8>(a, s);
-    }
-    valle_set_error("decode linear: combination not built (K=%d norm=%d epilogue=%d)", K, (int)norm, epilogue);
-    return VALLE_E_UNSUPPORTED;
 }

@@ -13,8 +13,7 @@ extern "C" int valle_attn_prefill(const void* qkv, void* out, const int32_t* cu_
 extern "C" int valle_model_create(const valle_config* cfg, const void* emb, const float* rope,
                                   const valle_layer_weights* layers_host, const void* final_norm,
                                   int n_cls, const void* const* head_w_host, const float* const* head_b_host,
-                                  const int32_t* head_n_host, const void* const* head_p_host,
-                                  const void* const* head_pn_host, valle_model** out) {
+                                  const int32_t* head_n_host, const void* const* head_pn_host, valle_model** out) {
     VALLE_REQUIRE(cfg && emb && rope && layers_host && final_norm && out, VALLE_E_ARG, "valle_model_create: null pointer");
     VALLE_REQUIRE(cfg->n_heads > 0 && cfg->d_model % cfg->n_heads == 0 && cfg->d_model / cfg->n_heads == 64,
                   VALLE_E_UNSUPPORTED, "valle_model_create: head_dim must be 64 (d_model %d, heads %d)", cfg->d_model, cfg->n_heads);
@@ -29,13 +28,11 @@ extern "C" int valle_model_create(const valle_config* cfg, const void* emb, cons
     m->head_w = (const void**)malloc(sizeof(void*) * (n_cls > 0 ? n_cls : 1));
     m->head_b = (const float**)malloc(sizeof(float*) * (n_cls > 0 ? n_cls : 1));
     m->head_n = (int32_t*)malloc(sizeof(int32_t) * (n_cls > 0 ? n_cls : 1));
-    m->head_p = (const void**)malloc(sizeof(void*) * (n_cls > 0 ? n_cls : 1));
     m->head_pn = (const void**)malloc(sizeof(void*) * (n_cls > 0 ? n_cls : 1));
     for (int k = 0; k < n_cls; ++k) {
         m->head_w[k] = head_w_host[k];
         m->head_b[k] = head_b_host ? head_b_host[k] : nullptr;
         m->head_n[k] = head_n_host[k];
-        m->head_p[k] = head_p_host ? head_p_host[k] : nullptr;
         m->head_pn[k] = head_pn_host ? head_pn_host[k] : nullptr;
     }
     *out = m;
@@ -44,7 +41,7 @@ extern "C" int valle_model_create(const valle_config* cfg, const void* emb, cons
 
 extern "C" void valle_model_destroy(valle_model* m) {
     if (!m) return;
-    free(m->layers); free((void*)m->head_w); free((void*)m->head_b); free(m->head_n); free((void*)m->head_p); free((void*)m->head_pn); free(m);
+    free(m->layers); free((void*)m->head_w); free((void*)m->head_b); free(m->head_n); free((void*)m->head_pn); free(m);
 }
 
 // ------------------------------------------------------------------ small helpers
@@ -99,7 +96,7 @@ __global__ __launch_bounds__(128) void dec_prepare_frag_kernel(const bf16* __res
 #pragma unroll
         for (int e = 0; e < 8; ++e) q2 = fmaf((float)v[e], (float)v[e], q2);
         q2 += __shfl_xor(q2, 1, 64);                                   // the two 8-column halves of a 16-column tile
-        *reinterpret_cast<bf16x8*>(xf + ((((c >> 5) << 6) + (((c >> 3) & 3) << 4) + b) << 3)) = v;
+        *reinterpret_cast<bf16x8*>(xf + (size_t)(b >> 4) * 16 * d + ((((c >> 5) << 6) + (((c >> 3) & 3) << 4) + (b & 15)) << 3)) = v;
         if ((threadIdx.x & 1) == 0) ssq[(size_t)b * (d >> 4) + (c >> 4)] = q2;
     }
 }
@@ -185,8 +182,8 @@ extern "C" size_t valle_decode_workspace_bytes(const valle_model* m, int B) {
     t += align_up((size_t)B * f * es, 256);            // ff
     t += align_up((size_t)B * 2048 * sizeof(float), 256);  // logits
     t += align_up((size_t)(B + 1) * sizeof(int32_t), 256) * 2 + align_up((size_t)B * sizeof(int32_t), 256);
-    t += align_up((size_t)16 * (d / 16) * sizeof(float), 256);   // per-tile sums of squares (wave-streaming path)
-    t += align_up((size_t)16 * d * es, 256) * 2 + align_up((size_t)16 * f * es, 256);  // its 16-row fragment-order x, att, ff
+    t += align_up((size_t)32 * (d / 16) * sizeof(float), 256);   // per-tile sums of squares (wave-streaming path)
+    t += align_up((size_t)32 * d * es, 256) * 2 + align_up((size_t)32 * f * es, 256);  // its fragment-order x, att, ff (16-row tiles)
     return t;
 }
 
@@ -212,18 +209,16 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
     float* lg_ws = (float*)ws.take((size_t)B * 2048 * sizeof(float));
     int32_t* pos = (int32_t*)ws.take((size_t)(B + 1) * sizeof(int32_t));
     int32_t* cu = (int32_t*)ws.take((size_t)(B + 1) * sizeof(int32_t));
-    float* ssq = (float*)ws.take((size_t)16 * (d / 16) * sizeof(float));
-    // the wave-streaming path keeps its activations as 16-row fragment-order matrices whatever B is
-    bf16* xf = (bf16*)ws.take((size_t)16 * d * es);
-    bf16* attf = (bf16*)ws.take((size_t)16 * d * es);
-    bf16* fff = (bf16*)ws.take((size_t)16 * f * es);
+    float* ssq = (float*)ws.take((size_t)32 * (d / 16) * sizeof(float));
+    // the wave-streaming path keeps its activations as 16-row fragment-order matrices (one or two of them)
+    bf16* xf = (bf16*)ws.take((size_t)32 * d * es);
+    bf16* attf = (bf16*)ws.take((size_t)32 * d * es);
+    bf16* fff = (bf16*)ws.take((size_t)32 * f * es);
     VALLE_REQUIRE(ws.ok, VALLE_E_WORKSPACE, "valle_ar_decode: workspace %zu B too small (need %zu)", workspace_bytes,
                   valle_decode_workspace_bytes(m, B));
     hipStream_t s = (hipStream_t)stream;
-    const bool wavepath = (dt == VALLE_BF16) && B <= 16 && (d == 256 || d == 1024) && (f == 1024 || f == 4096) &&
+    const bool wavepath = (dt == VALLE_BF16) && B <= 32 && (d == 256 || d == 1024) && (f == 1024 || f == 4096) &&
                           m->layers[0].pn_qkv && m->layers[0].p_o && m->layers[0].pn_gu && m->layers[0].p_down && m->head_pn[st->head];
-    const bool fused = !wavepath && (dt == VALLE_BF16) && B <= 32 && (d == 256 || d == 1024) && (f == 256 || f == 1024 || f == 4096) &&
-                       m->layers[0].p_qkv && m->layers[0].p_o && m->layers[0].p_gu && m->layers[0].p_down && m->head_p[st->head];
     int rc;
     for (int step = 0; step < n_steps; ++step) {
         float* lg = logits_out ? logits_out + (size_t)step * B * ld_logits : lg_ws;
@@ -259,24 +254,6 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
                 DecWArgs dn{};
                 dn.x = fff; dn.W = (const bf16*)w.p_down; dn.resid = xf; dn.out = xf; dn.B = B; dn.N = d; dn.K = f; dn.ssq_out = ssq;
                 RUN(valle_dec_wave_linear(dn, VALLE_EPI_RESID, s));
-            } else if (fused) {
-                DecArgs a{};
-                a.x = (const bf16*)x; a.norm_w = (const bf16*)w.ln1; a.eps = c.rms_eps; a.W = (const bf16*)w.p_qkv;
-                a.out = qkv; a.ldo = 3 * d; a.B = B; a.N = 3 * d; a.K = d;
-                a.rope = m->rope; a.pos = pos; a.ctx_len = st->ctx_len; a.slot = st->cache_slot;
-                a.kc = (bf16*)kc; a.vc = (bf16*)vc; a.cache_T = st->cache_T; a.H = H; a.d = d;
-                RUN(valle_dec_linear_bf16(a, DEC_EPI_QKV, s));
-                RUN(valle_attn_decode_launch(qkv, kc, vc, st->ctx_len, st->cache_slot, att, B, H, Dh, st->cache_T, 1, dt, s));
-                DecArgs o{};
-                o.x = (const bf16*)att; o.W = (const bf16*)w.p_o; o.resid = (const bf16*)x; o.out = x; o.ldo = d; o.B = B; o.N = d; o.K = d;
-                RUN(valle_dec_linear_bf16(o, VALLE_EPI_RESID, s));
-                DecArgs g{};
-                g.x = (const bf16*)x; g.norm_w = (const bf16*)w.ln2; g.eps = c.rms_eps; g.W = (const bf16*)w.p_gu;
-                g.out = ff; g.ldo = f; g.B = B; g.N = 2 * f; g.K = d;
-                RUN(valle_dec_linear_bf16(g, VALLE_EPI_GEGLU, s));
-                DecArgs dn{};
-                dn.x = (const bf16*)ff; dn.W = (const bf16*)w.p_down; dn.resid = (const bf16*)x; dn.out = x; dn.ldo = d; dn.B = B; dn.N = d; dn.K = f;
-                RUN(valle_dec_linear_bf16(dn, VALLE_EPI_RESID, s));
             } else {
                 RUN(valle_rmsnorm(x, w.ln1, h, B, d, c.rms_eps, dt, s));
                 RUN(valle_gemm(h, w.w_qkv, nullptr, nullptr, qkv, B, 3 * d, d, 3 * d, VALLE_EPI_STORE, dt, s));
@@ -293,11 +270,6 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
             hd.x = xf; hd.W = (const bf16*)m->head_pn[st->head]; hd.bias = m->head_b[st->head]; hd.out = lg; hd.ldo = ldl;
             hd.B = B; hd.N = st->vocab; hd.K = d; hd.eps = c.rms_eps; hd.norm = 1; hd.ssq_in = ssq;
             RUN(valle_dec_wave_linear(hd, VALLE_EPI_F32OUT, s));
-        } else if (fused) {
-            DecArgs hd{};
-            hd.x = (const bf16*)x; hd.norm_w = (const bf16*)m->final_norm; hd.eps = c.rms_eps; hd.W = (const bf16*)m->head_p[st->head];
-            hd.bias = m->head_b[st->head]; hd.out = lg; hd.ldo = ldl; hd.B = B; hd.N = st->vocab; hd.K = d;
-            RUN(valle_dec_linear_bf16(hd, VALLE_EPI_F32OUT, s));
         } else {
             RUN(valle_rmsnorm(x, m->final_norm, h, B, d, c.rms_eps, dt, s));
             RUN(valle_gemm(h, m->head_w[st->head], m->head_b[st->head], nullptr, lg, B, st->vocab, d, ldl, VALLE_EPI_F32OUT, dt, s));

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) q2 = fmaf((float)v[e], (float)v[e], q2);
             q2 += __shfl_xor(q2, 1, 64);
-            *reinterpret_cast<bf16x8*>(a.nx_x + ((((c >> 5) << 6) + (((c >> 3) & 3) << 4) + item) << 3)) = v;
+            *reinterpret_cast<bf16x8*>(a.nx_x + (size_t)(item >> 4) * 16 * a.nx_d + ((((c >> 5) << 6) + (((c >> 3) & 3) << 4) + (item & 15)) << 3)) = v;
             if ((tid & 1) == 0) a.nx_ssq[(size_t)item * (a.nx_d >> 4) + (c >> 4)] = q2;
         }
         if (tid == 0) a.nx_pos[item] = (a.nx_pos0 ? a.nx_pos0[item] : 0) + n_prev;   // position of token index n_prev

@@ -188,22 +188,21 @@ class Base:
             b[f"down{l}"] = sd[p + "mlp.down_proj.weight"].to(dev, dt).contiguous()
             b[f"ln1_{l}"] = sd[p + "input_layernorm.weight"].to(dev, dt).contiguous()
             b[f"ln2_{l}"] = sd[p + "post_attention_layernorm.weight"].to(dev, dt).contiguous()
-            packed = [None] * 6
+            packed = [None] * 4
             if dt == torch.bfloat16 and d % 64 == 0:
-                for j, n in enumerate(("qkv", "o", "gu", "down")):
+                for j, n in enumerate(("o", "down")):
                     b[f"p_{n}{l}"] = pack_stream_order(b[f"{n}{l}"])
                     packed[j] = b[f"p_{n}{l}"].data_ptr()
                 # norm weight folded in (product in fp32 of the bf16-rounded factors, rounded to bf16 once)
                 for j, (n, ln) in enumerate((("qkv", "ln1_"), ("gu", "ln2_"))):
                     folded = (b[f"{n}{l}"].float() * b[f"{ln}{l}"].float()[None, :]).to(dt)
                     b[f"pn_{n}{l}"] = pack_stream_order(folded)
-                    packed[4 + j] = b[f"pn_{n}{l}"].data_ptr()
+                    packed[2 + j] = b[f"pn_{n}{l}"].data_ptr()
             layers[l] = L.LayerWeights(b[f"ln1_{l}"].data_ptr(), b[f"qkv{l}"].data_ptr(), b[f"o{l}"].data_ptr(),
                                        b[f"ln2_{l}"].data_ptr(), b[f"gu{l}"].data_ptr(), b[f"down{l}"].data_ptr(), *packed)
         b["norm"] = sd["model.norm.weight"].to(dev, dt).contiguous()
         n_cls = len(self.cls_tokens)
-        hw, hb, hn, hp = (C.c_void_p * n_cls)(), (C.c_void_p * n_cls)(), (C.c_int32 * n_cls)(), (C.c_void_p * n_cls)()
-        hpn = (C.c_void_p * n_cls)()
+        hw, hb, hn, hpn = (C.c_void_p * n_cls)(), (C.c_void_p * n_cls)(), (C.c_int32 * n_cls)(), (C.c_void_p * n_cls)()
         for k in range(n_cls):
             b[f"hw{k}"] = sd[f"classifiers.proj.{k}.weight"].to(dev, dt).contiguous()
             hw[k] = b[f"hw{k}"].data_ptr()
@@ -214,18 +213,16 @@ class Base:
             else:
                 hb[k] = None
             hn[k] = self.cls_tokens[k]
-            hp[k] = hpn[k] = None
+            hpn[k] = None
             if dt == torch.bfloat16 and k == 0:      # the AR head is the one the decode loop streams
-                b[f"hp{k}"] = pack_stream_order(b[f"hw{k}"])
-                hp[k] = b[f"hp{k}"].data_ptr()
                 b[f"hpn{k}"] = pack_stream_order((b[f"hw{k}"].float() * b["norm"].float()[None, :]).to(dt))
                 hpn[k] = b[f"hpn{k}"].data_ptr()
         cfg = L.Config(d, H, self.n_layers, ff, L.dtype_code(dt), 1e-6, self.max_position_embeddings)
         handle = C.c_void_p()
         L.check(lib.valle_model_create(C.byref(cfg), L.ptr(b["emb"]), L.ptr(b["rope"]), layers, L.ptr(b["norm"]), n_cls,
-                                       hw, hb, hn, hp, hpn, C.byref(handle)))
+                                       hw, hb, hn, hpn, C.byref(handle)))
         self._handle = handle
-        self._keep = [layers, hw, hb, hn, hp, hpn]
+        self._keep = [layers, hw, hb, hn, hpn]
 
     # -------------------------------------------------------------------- sequence planning
     def plan(self, phns_list, lang_list, proms_list, resps_list, quant_level, *, timestep=False) -> Plan:
