@@ -451,3 +451,24 @@ def test_attn_decode_bf16_vs_fp64(gpu_device, cache_T, ctx):
     got = out.double().cpu()
     assert torch.isfinite(got).all()
     assert ((got - want).norm() / want.norm()).item() < 1e-2
+
+
+def test_reference_surface_inputs_forward_super_sample(gpu_device):
+    """The lower-level surface other reference code uses (ar_nar.py:36-37, base.py:560, :1280):
+    model.inputs(...) -> model.forward_super(inputs) -> model.sample(logits, ...) gives the same logits as the
+    keyword route and, at temperature 0 with the filters off, the arg-max of each row."""
+    z = load_golden("tiny_fwd")
+    phns, proms, langs = golden_inputs(z)
+    m = hip_model("tiny")
+    resps = [torch.from_numpy(z[f"nar_resp_{i}"]) for i in range(2)]
+    inp = m.inputs(phns_list=phns, proms_list=proms, resps_list=resps, lang_list=langs, quant_levels=[3, 3])
+    a = m.forward_super(inp)
+    b = m.forward_super(dict(phns_list=phns, lang_list=langs, proms_list=proms, resps_list=resps), quant_levels=[3, 3])
+    for x, y in zip(a.logits, b.logits):
+        assert torch.equal(x, y)
+    tails = [l[-r.shape[0]:] for l, r in zip(a.logits, resps)]
+    s = m.sample(tails, prev_list=[r[:, -1] for r in resps], temperature=0.0, top_no=0.0)
+    for ids, l in zip(s.ids, tails):
+        assert torch.equal(ids.cpu(), l.argmax(-1).cpu())
+    ar = m.sample(a.logits, temperature=0.0, top_no=0.0)          # AR form: last row only
+    assert [int(i[0]) for i in ar.ids] == [int(l[-1].argmax()) for l in a.logits]

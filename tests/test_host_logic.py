@@ -132,3 +132,24 @@ def test_weights_file_roundtrip_in_reference_format(tmp_path):
     import pytest
     with pytest.raises(NotImplementedError):
         torch_load(tmp_path / "model.pth")
+
+
+def test_inputs_structure_matches_reference_layout():
+    """Base.inputs builds the reference's (name, value) tuple lists (models/base.py:597-649) and
+    plan_from_inputs turns them into the same plan as the keyword form."""
+    import numpy as np
+    import torch
+    from vall_e_amd.config import tiny_model
+    from vall_e_amd.models import get_model
+    from vall_e_amd.synth import synth_batch
+    m = get_model(tiny_model())
+    phns, proms, langs = synth_batch(3, 2, n_phn=6, n_prom=5)
+    resps = [torch.randint(0, 1024, (7, 2)), torch.randint(0, 1024, (4, 2))]
+    inp = m.inputs(phns_list=phns, proms_list=proms, resps_list=resps, lang_list=langs, task_list=["tts"] * 2, quant_levels=[2, 2])
+    assert [n for n, _ in inp[0]] == ["task", "phn", "lang", "quant_level", "prom", "resp", "classifier_level"]
+    assert inp[0][0] == ("task", "tts") and inp[0][-1] == ("classifier_level", "NAR:1:2")
+    a, b = m.plan_from_inputs(inp), m.plan(phns, langs, proms, resps, 2)
+    assert np.array_equal(a.idx, b.idx) and np.array_equal(a.pos, b.pos) and a.head == b.head and a.lens == b.lens
+    nl = m.inputs(phns_list=phns, proms_list=proms, resps_list=[r[:, 0] for r in resps], lang_list=langs, time_list=[0.5, 0.5], quant_levels=[0, 0])
+    assert nl[1][-1] == ("classifier_level", "NAR:0:0")
+    assert m.plan_from_inputs(nl).head == m.cls_names.index("NAR:0:0")

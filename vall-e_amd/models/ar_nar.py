@@ -43,10 +43,17 @@ def _host_codes(tensors):
 class AR_NAR(Base):
     # ---------------------------------------------------------------- lower-level surface
     def forward_super(self, inputs, quant_levels=None, state=None, output_attentions=False, output_hidden_states=False):
-        """Base.forward on an explicit batch description: ``inputs`` is a dict with the keyword
-        lists of ``plan`` (phns_list, lang_list, proms_list, resps_list) -- all rows' logits."""
+        """Base.forward on an explicit batch description -- all rows' logits.  ``inputs`` is either what
+        ``self.inputs(...)`` returns (the reference's list of (name, value) tuples per utterance, ar_nar.py:36-37)
+        or a dict with the keyword lists of ``plan`` (phns_list, lang_list, proms_list, resps_list)."""
         if output_attentions or output_hidden_states or state is not None:
             raise NotImplementedError("attentions / hidden states / external state are not exposed")
+        if isinstance(inputs, (list, tuple)):
+            plan = self.plan_from_inputs(inputs)
+            rows, off = self.tail_rows(plan, plan.lens)
+            lg = self.forward_dense(plan, rows)
+            V = self.cls_tokens[plan.head]
+            return Logits([lg[off[i]:off[i + 1], :V] for i in range(plan.B)], None, inputs, None, None, None)
         q = 0 if quant_levels is None else int(quant_levels[0])
         if quant_levels is not None and any(int(x) != q for x in quant_levels):
             raise NotImplementedError("one quant level per batch")

@@ -225,6 +225,51 @@ class Base:
         self._keep = [layers, hw, hb, hn, hpn]
 
     # -------------------------------------------------------------------- sequence planning
+    def inputs(self, phns_list=None, text_list=None, proms_list=None, resps_list=None, lang_list=None, tone_list=None,
+               len_list=None, task_list=None, time_list=None, quant_levels=None):
+        """The reference's per-utterance list of (name, value) tuples for the TTS layout (base.py:560-649):
+        task, phn, lang, quant_level, prom, resp, classifier_level -- accepted by ``forward_super``."""
+        if text_list is not None or tone_list is not None or len_list is not None:
+            raise NotImplementedError("raw-text / tone / len inputs are outside the built path")
+        first = next(l for l in (phns_list, proms_list, resps_list) if l)
+        B = len(first)
+        out = [[] for _ in range(B)]
+        for i in range(B):
+            q = int(quant_levels[i]) if quant_levels is not None else 0
+            task = task_list[i] if task_list is not None else "tts"
+            if task != "tts":
+                raise NotImplementedError(f"task {task!r}: only 'tts' is built")
+            timestep = time_list[i] if time_list is not None else None
+            out[i].append(("task", task))
+            if phns_list is not None and phns_list[i] is not None:
+                out[i].append(("phn", phns_list[i]))
+            if "lang" in self.capabilities and lang_list is not None and lang_list[i] is not None:
+                out[i].append(("lang", lang_list[i]))
+            out[i].append(("quant_level", torch.tensor([q], dtype=torch.int16)))
+            level = "AR:0:0" if q == 0 else f"NAR:{q-1}:{q}"
+            if proms_list is not None and proms_list[i] is not None:
+                out[i].append(("prom", proms_list[i]))
+            if timestep is not None:
+                level = "NAR:0:0"                                           # base.py:628
+            if resps_list is not None and resps_list[i] is not None:
+                out[i].append(("resp", resps_list[i]))
+            out[i].append(("classifier_level", level))
+        return out
+
+    def plan_from_inputs(self, inputs):
+        """``inputs()`` tuples -> Plan.  One classifier level per batch (one head per dense pass)."""
+        col = {k: [dict((n, v) for n, v in item if n != "task").get(k) for item in inputs] for k in ("phn", "lang", "prom", "resp")}
+        levels = {dict(item)["classifier_level"] for item in inputs}
+        qs = {int(dict(item)["quant_level"][0]) for item in inputs}
+        if len(levels) != 1 or len(qs) != 1:
+            raise NotImplementedError("one classifier level per batch")
+        level, q = levels.pop(), qs.pop()
+        resps = col["resp"] if any(r is not None for r in col["resp"]) else [None] * len(inputs)
+        return self.plan(col["phn"] if any(p is not None for p in col["phn"]) else None,
+                         col["lang"] if any(p is not None for p in col["lang"]) else None,
+                         col["prom"] if any(p is not None for p in col["prom"]) else None,
+                         resps, q, timestep=(level == "NAR:0:0"))
+
     def plan(self, phns_list, lang_list, proms_list, resps_list, quant_level, *, timestep=False) -> Plan:
         """TTS layout phn, lang, quant_level, prom, resp with a ``sep`` row between segments
         (base.py:603-649, :101-110); classifier level per base.py:618/:628; position ids restart per
@@ -374,6 +419,25 @@ class Base:
         return L.SampleParams(float(temperature), int(top_k), float(top_p), float(min_p), float(top_no),
                               float(repetition_penalty), float(repetition_penalty_decay), float(length_penalty),
                               int(self.stop_token), int(rep_pen_passes), int(seed), int(offset))
+
+    def sample(self, logits, prev_list=None, **sampling_kwargs):
+        """``Base.sample`` (base.py:1280-1430): logits = list of per-utterance (rows, vocab) tensors; with
+        ``prev_list`` of equal row counts the call is a NAR one (all rows sampled), otherwise only the last
+        ``causal_size`` row of each utterance is (AR).  -> Sampled(ids, logits, scores, entropy=None)."""
+        B = len(logits)
+        V = int(logits[0].shape[-1])
+        if prev_list is not None and all(len(p) == l.shape[0] for p, l in zip(prev_list, logits)):
+            nar, rows = 1, logits
+        else:
+            nar, rows = 0, [l[-self.causal_size:] for l in logits]              # base.py:1358-1360
+        counts = [r.shape[0] for r in rows]
+        off = np.concatenate(([0], np.cumsum(counts))).astype(np.int32)
+        ld = _round_up(V, 8)
+        flat = torch.zeros((int(off[-1]), ld), dtype=torch.float32, device=self.device)
+        flat[:, :V] = torch.cat([r.to(self.device, torch.float32) for r in rows])
+        ids, scores = self.sample_rows(flat, V, off, prev_list, nar_mode=nar, params=self.sample_params(**sampling_kwargs))
+        cut = lambda t: [t[off[i]:off[i + 1]] for i in range(B)]
+        return Sampled(cut(ids.long()), logits, cut(scores), None)
 
     def sample_rows(self, logits, vocab, row_off, prev_list, nar_mode, params, dev=None):
         """valle_sample over packed logits rows; row_off = per-utterance row offsets (B+1).
