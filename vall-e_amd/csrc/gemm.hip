@@ -309,11 +309,135 @@ __global__ __launch_bounds__(256) void gemm_glds_n64_bf16_kernel(const bf16* __r
     gemm_epilogue<bf16, EPI, 4, 2>(acc, n0, m0 + wave * 32, fr, fq, bias, resid, Cout, M, N, ldc);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide GEMMs (QKV, gate/up): 256 x 256 tile, BK = 64, 8 waves in two groups that ping-pong on the matrix
+// core.  Every wave owns a 128(n) x 64(m) block of the output = four 64 x 32 quadrants; per K-tile it
+// alternates a READ slot (fragment reads for the next quadrant, or the LDS-DMA of a later tile) and an MFMA
+// slot (one quadrant, 16 MFMAs), with a workgroup barrier after every slot.  Group 1 (waves 4-7, which share
+// their SIMDs with waves 0-3) runs one slot behind group 0, so while one wave of a SIMD issues MFMAs the other
+// one reads LDS.  Two 64-KB LDS buffers (swizzled linear image as above); tile t+1 is staged into the other
+// buffer during the first three read slots of tile t -- that buffer's last fragment reads (tile t-1) were
+// waited for (lgkmcnt(0) before the barrier that ends a read slot) before tile t began -- and is waited for
+// (vmcnt(0)) in the 4th read slot, two barriers before its first read.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W,
+                                                              const void* __restrict__ bias, const bf16* resid,
+                                                              void* Cout, int M, int N, int K, int ldc) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * 65536];        // [buf][W 256 rows | X 256 rows] x 128 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wi = wave & 3;
+    const int nh = wi & 1, mq = (wi >> 1) + 2 * grp;                       // n half (128 rows), m quarter (64 rows)
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 256, m0 = blockIdx.y * 256;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging: a K-tile is 64 pieces of 8 rows (W: 0..31, X: 32..63); this wave issues pieces wave*8 .. +7
+    const bf16* src[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int piece = wave * 8 + j;
+        const int row = piece * 8 + (lane >> 3);                           // 0..255 W rows, 256..511 X rows
+        const int ch = (lane & 7) ^ (row & 7);
+        if (piece < 32) { int n = n0 + row; n = n < N ? n : N - 1; src[j] = W + (size_t)n * K + ch * 8; }
+        else { int m = m0 + row - 256; m = m < M ? m : M - 1; src[j] = X + (size_t)m * K + ch * 8; }
+    }
+    auto stage_part = [&](int kt, int buf, int j0, int j1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j >= j0 && j < j1)
+                __builtin_amdgcn_global_load_lds(src[j] + kt * 64, (lds_void*)&lds[buf * 65536 + (wave * 8 + j) * 1024], 16, 0, 0);
+    };
+    auto stage = [&](int kt, int buf) { stage_part(kt, buf, 0, 8); };
+    // fragment addressing: row = const + fr, so (row & 7) == (fr & 7) and the swizzle depends on the k-half only
+    const int sw0 = ((fq ^ (fr & 7)) << 4), sw1 = (((4 + fq) ^ (fr & 7)) << 4);
+    const int abase = (nh * 128 + fr) * 128, bbase = (256 + mq * 64 + fr) * 128;
+    bf16x8 A[4][2], B0[2][2], B1[2][2];
+    auto read_a = [&](const char* L, int i) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            A[rt][0] = *reinterpret_cast<const bf16x8*>(L + abase + (i * 64 + rt * 16) * 128 + sw0);
+            A[rt][1] = *reinterpret_cast<const bf16x8*>(L + abase + (i * 64 + rt * 16) * 128 + sw1);
+        }
+    };
+    auto read_b = [&](const char* L, int j, bf16x8 (&Bf)[2][2]) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            Bf[ct][0] = *reinterpret_cast<const bf16x8*>(L + bbase + (j * 32 + ct * 16) * 128 + sw0);
+            Bf[ct][1] = *reinterpret_cast<const bf16x8*>(L + bbase + (j * 32 + ct * 16) * 128 + sw1);
+        }
+    };
+    auto quad = [&](int i, int j, bf16x8 (&Bf)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+                    acc[i * 4 + rt][j * 2 + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[rt][hf], Bf[ct][hf], acc[i * 4 + rt][j * 2 + ct], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define PP_END_READ()  do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#define PP_END_MFMA()  __builtin_amdgcn_s_barrier()
+
+    const int nt = K / 64;
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();                            // group 1 runs one slot behind
+    for (int kt = 0; kt < nt; ++kt) {
+        const char* L = lds + (kt & 1) * 65536;
+        // tile kt+1 goes into the OTHER buffer, whose last reads (tile kt-1) ended before this iteration began;
+        // its 8 DMA pieces per wave are spread over the read slots (a piece costs ~60-100 cycles to issue)
+        const bool st = kt >= 1 && kt + 1 < nt;
+        read_a(L, 0); read_b(L, 0, B0);                                   // R1
+        if (st) stage_part(kt + 1, (kt + 1) & 1, 0, 2);
+        PP_END_READ();
+        quad(0, 0, B0);                                                   // M1
+        PP_END_MFMA();
+        read_b(L, 1, B1);                                                 // R2
+        if (st) stage_part(kt + 1, (kt + 1) & 1, 2, 5);
+        PP_END_READ();
+        quad(0, 1, B1);                                                   // M2
+        PP_END_MFMA();
+        read_a(L, 1);                                                     // R3
+        if (st) stage_part(kt + 1, (kt + 1) & 1, 5, 8);
+        PP_END_READ();
+        quad(1, 1, B1);                                                   // M3
+        PP_END_MFMA();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // R4: tile kt+1 has landed (my pieces)
+        __builtin_amdgcn_s_barrier();
+        quad(1, 0, B0);                                                   // M4
+        PP_END_MFMA();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+#undef PP_END_READ
+#undef PP_END_MFMA
+    gemm_epilogue<bf16, EPI, 8, 4>(acc, n0 + nh * 128, m0 + mq * 64, fr, fq, bias, resid, Cout, M, N, ldc);
+}
+
 static int gemm_glds_dispatch(const void* A, const void* W, const void* bias, const void* resid, void* C,
                               int M, int N, int K, int ldc, int epi, hipStream_t s) {
     if (N <= 1024 && epi == VALLE_EPI_RESID) {      // narrow outputs: smaller tile, whole rounds of workgroups
         dim3 g64(ceil_div(N, 64), ceil_div(M, 128));
         gemm_glds_n64_bf16_kernel<VALLE_EPI_RESID><<<g64, 256, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
+        VALLE_LAUNCH_CHECK();
+        return VALLE_OK;
+    }
+    // Wide outputs only: at K = 1024 (16 K-tiles) a one-workgroup-per-CU kernel pays its pipeline fill and its
+    // epilogue once per tile with nothing to overlap them, so it wins where the grid is several whole rounds of
+    // 256 workgroups (gate/up: +12 % over the 128^2 kernel) and loses on the QKV shape (2.25 rounds: -10 %).
+    if (N >= 4096 && M >= 1024 && (epi == VALLE_EPI_STORE || epi == VALLE_EPI_GEGLU)) {
+        dim3 g256(ceil_div(N, 256), ceil_div(M, 256));
+        if (epi == VALLE_EPI_STORE) gemm_pp256_bf16_kernel<VALLE_EPI_STORE><<<g256, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
+        else gemm_pp256_bf16_kernel<VALLE_EPI_GEGLU><<<g256, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
         VALLE_LAUNCH_CHECK();
         return VALLE_OK;
     }
