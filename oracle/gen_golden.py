@@ -18,6 +18,7 @@ Scenarios (names = file stems under tests/golden/):
   tiny_sampling     tiny model: greedy AR under rep-pen / length-pen / top-k / top-p, stop-token path
   tiny_cfg          tiny model: AR + NAR with cfg_strength > 0
   tiny_narlen       tiny model: NAR-len demasking (max_steps 6) + NAR levels
+  tiny_len          tiny model with the `len` capability: duration prediction (task "len"), per-step logits
   full_b1           BASELINE configs[0]: full model, qnt.enc prompt, 19 phonemes, AR 24 + NAR
   full_b3           full model, ragged B=3, AR 12 + NAR
   full_narlen       full model, B=2, NAR-len max_steps 4
@@ -92,9 +93,10 @@ def get_ref_model(kind, dtype=torch.float32, **synth_kw):
     key = (kind, dtype, tuple(sorted(synth_kw.items())))
     if key in _models:
         return _models[key]
-    mcfg = vcfg.repo_default_model() if kind == "full" else vcfg.tiny_model()
-    model = rh.build_reference_model(size=mcfg.size)
-    sd = synth_state_dict(mcfg, WEIGHT_SEED, **synth_kw)
+    mcfg = {"full": vcfg.repo_default_model, "tiny": vcfg.tiny_model, "tiny_len": vcfg.tiny_len_model}[kind]()
+    model = rh.build_reference_model(size=mcfg.size, capabilities=list(mcfg.capabilities))
+    synth_kw = dict(synth_kw)
+    sd = synth_state_dict(mcfg, synth_kw.pop("weight_seed", WEIGHT_SEED), **synth_kw)
     missing = model.load_state_dict(sd, strict=True)
     model = model.to(dtype).eval()
     _models.clear()  # keep one model in memory at a time
@@ -412,6 +414,29 @@ def scen_tiny_narlen():
     narlen_scenario("tiny_narlen", "tiny", phns, proms, langs, lens=[18, 25], max_steps=6)
 
 
+def scen_tiny_len():
+    """Duration prediction (task ``len``, ar_nar.py:640-692) the way inference.py:329 calls it.  Two weight
+    seeds: one whose utterances stop at different steps (the loop keeps appending to stopped ones), one where
+    all stop early."""
+    ref = rh.load_reference()
+    for name, wseed in (("tiny_len", 2030), ("tiny_len_stop", 2003)):
+        model, mcfg = get_ref_model("tiny_len", weight_seed=wseed)
+        phns, proms, langs = synth_batch(71, 3, n_phn=10, n_prom=16, ragged=True)
+        d = input_arrays(phns, proms, langs)
+        with Recorder(ref) as rec, torch.inference_mode():
+            out = model(task_list=["len"] * 3, **to_model_inputs(phns, proms, langs), disable_tqdm=True, max_duration=5)
+        gap = min(top2_gap(r) for c in rec.calls for r in c["logits"])
+        if gap <= MIN_GAP:
+            raise RuntimeError(f"{name}: top-2 margin {gap:.2e} too small, pick another weight seed")
+        d["lens"] = np.array(out, dtype=np.int64)
+        d["n_steps"] = np.int64(len(rec.calls))
+        for n, c in enumerate(rec.calls):
+            d[f"logits_step{n}"] = torch.stack(c["logits"])
+        d["min_gap"] = np.float64(gap)
+        d["weight_seed"] = np.int64(wseed)
+        save(name, **d)
+
+
 def scen_full_b1():
     ref = rh.load_reference()
     phns, proms, langs = qnt_inputs()
@@ -461,6 +486,7 @@ SCENARIOS = {
     "tiny_sampling": scen_tiny_sampling,
     "tiny_cfg": scen_tiny_cfg,
     "tiny_narlen": scen_tiny_narlen,
+    "tiny_len": scen_tiny_len,
     "full_b1": scen_full_b1,
     "full_b3": scen_full_b3,
     "full_narlen": scen_full_narlen,

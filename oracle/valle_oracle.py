@@ -49,14 +49,15 @@ class Plan:
     out_len: int         # length of the output segment
 
 
-def plan_sequence(phn, lang, prom, resp, quant_level, *, timestep=False, task="tts", unified_pos=False):
+def plan_sequence(phn, lang, prom, resp, quant_level, *, timestep=False, task="tts", unified_pos=False, len_ids=None):
     """Ordered segments of one utterance + per-segment position ids.
 
     TTS order: phn, lang, quant_level, prom, resp (base.py:605-649); every segment but the
     last is followed by one ``sep`` row (base.py:101-110), which the position ids of the
-    non-output segments count as one extra position (base.py:984)."""
-    if task != "tts":
-        raise NotImplementedError("oracle covers the tts layout (AR, NAR, NAR-len)")
+    non-output segments count as one extra position (base.py:984).  The ``len`` task
+    (base.py:652-683) has the same order with the length digits in place of resp and its own head."""
+    if task not in ("tts", "len"):
+        raise NotImplementedError("oracle covers the tts layout (AR, NAR, NAR-len) and the len task")
     segs = []
     if phn is not None:
         segs.append(Segment("phn", phn.long()))
@@ -68,20 +69,25 @@ def plan_sequence(phn, lang, prom, resp, quant_level, *, timestep=False, task="t
         segs.append(Segment("prom", prom.long()))
     if timestep:
         head = "NAR:0:0"
-    if resp is not None:
+    if task == "len":
+        head = "len"
+        if len_ids is not None:
+            segs.append(Segment("len", len_ids.long()))
+    elif resp is not None:
         segs.append(Segment("resp", resp.long()))
+    out_kind = "len" if task == "len" else "resp"                      # task_outputs, base.py:67-73
     pos = []
     for s in segs:
         n = s.ids.shape[0]
-        pos.append(torch.arange(n + (0 if s.kind == "resp" else 1)))
+        pos.append(torch.arange(n + (0 if s.kind == out_kind else 1)))
     pos = torch.cat(pos)
     T = sum(s.ids.shape[0] for s in segs) + len(segs) - 1
-    if segs[-1].kind != "resp":   # no output segment: the trailing +1 has no sep row behind it
+    if segs[-1].kind != out_kind:   # no output segment: the trailing +1 has no sep row behind it
         pos = pos[:T]
     if unified_pos:
         pos = torch.arange(T)
     assert pos.shape[0] == T, (pos.shape, T)
-    return Plan(segs, head, quant_level, pos, segs[-1].ids.shape[0] if segs[-1].kind == "resp" else 0)
+    return Plan(segs, head, quant_level, pos, segs[-1].ids.shape[0] if segs[-1].kind == out_kind else 0)
 
 
 # ------------------------------------------------------------------------- samplers
@@ -364,6 +370,32 @@ class Oracle:
         return [plan_sequence(None if phns is None else phns[i], None if langs is None else langs[i],
                               None if proms is None else proms[i], resps[i], q, timestep=timestep,
                               unified_pos=self.unified_pos) for i in range(B)]
+
+    # -- duration prediction (ar_nar.py:640-692, len task) ------------------------------------
+    def predict_len(self, phns, proms, langs, *, return_logits=False):
+        """<= 10 greedy steps over the 11-token ``len`` head, sequences seeded with digit 0.  Like the
+        reference it keeps appending to utterances that already stopped until ALL have, and the final
+        integer drops every stop token (10) but keeps digits that came after one."""
+        B = len(phns)
+        stop = 10
+        seqs = [torch.tensor([0]) for _ in range(B)]
+        stopped = [False] * B
+        kept = []
+        for _ in range(10):
+            plans = [plan_sequence(phns[i], None if langs is None else langs[i], None if proms is None else proms[i],
+                                   None, 0, task="len", unified_pos=self.unified_pos, len_ids=seqs[i]) for i in range(B)]
+            logits = self.forward(plans, rows=[1] * B)
+            if return_logits:
+                kept.append(torch.stack([l[-1].float() for l in logits]))
+            for i in range(B):
+                tok = int(logits[i][-1:].argmax(dim=1)[0])
+                tok = min(tok, stop)
+                stopped[i] = stopped[i] or tok == stop
+                seqs[i] = torch.cat([seqs[i], torch.tensor([tok])])
+            if all(stopped):
+                break
+        out = [int("".join(str(int(t)) for t in s if int(t) != stop)) for s in seqs]
+        return (out, kept, seqs) if return_logits else out
 
     # -- AR (ar_nar.py:588-890, tts task) ---------------------------------------------
     def ar(self, phns, proms, langs, *, max_duration=500, use_cache=False, return_logits=False, generator=None, **kw):

@@ -45,7 +45,7 @@ _cache = {}
 
 def model_cfg(kind):
     from vall_e_amd import config as vcfg
-    return vcfg.repo_default_model() if kind == "full" else vcfg.tiny_model()
+    return {"full": vcfg.repo_default_model, "tiny": vcfg.tiny_model, "tiny_len": vcfg.tiny_len_model}[kind]()
 
 
 def synth_weights(kind, **kw):
@@ -54,7 +54,8 @@ def synth_weights(kind, **kw):
     if key not in _cache:
         if len(_cache) > 2:
             _cache.clear()
-        _cache[key] = synth_state_dict(model_cfg(kind), 1234, **kw)
+        kw = dict(kw)
+        _cache[key] = synth_state_dict(model_cfg(kind), kw.pop("weight_seed", 1234), **kw)
     return _cache[key]
 
 

@@ -153,3 +153,41 @@ def test_inputs_structure_matches_reference_layout():
     nl = m.inputs(phns_list=phns, proms_list=proms, resps_list=[r[:, 0] for r in resps], lang_list=langs, time_list=[0.5, 0.5], quant_levels=[0, 0])
     assert nl[1][-1] == ("classifier_level", "NAR:0:0")
     assert m.plan_from_inputs(nl).head == m.cls_names.index("NAR:0:0")
+
+
+def test_len_task_plan_and_inputs():
+    """Task ``len`` (base.py:652-683): layout phn|lang|quant_level|prom|len, head ``len``, the len segment is the
+    output one (no trailing +1 in its position ids); embeddings and positions equal the oracle's."""
+    from vall_e_amd.models import get_model
+    z = load_golden("tiny_len")
+    phns, proms, langs = golden_inputs(z)
+    ws = int(z["weight_seed"])
+    m = get_model(model_cfg("tiny_len"), training=False)
+    m.load_state_dict(synth_weights("tiny_len", weight_seed=ws))
+    o = vo.Oracle(model_cfg("tiny_len"), synth_weights("tiny_len", weight_seed=ws))
+    seqs = [torch.tensor([0, 3]), torch.tensor([0]), torch.tensor([0, 1, 10, 4])]
+    plan = m.plan(phns, langs, proms, [None] * 3, 0, task="len", len_list=seqs)
+    assert m.cls_names[plan.head] == "len" and m.cls_tokens[plan.head] == 11 and plan.out_len == [2, 1, 4]
+    E = table(m)
+    off = 0
+    for i in range(3):
+        p = vo.plan_sequence(phns[i], langs[i], proms[i], None, 0, task="len", len_ids=seqs[i])
+        want = o.embed_sequence(p)
+        T = want.shape[0]
+        idx = plan.idx[off:off + T]
+        assert (idx[:, 1:] == -1).all()
+        np.testing.assert_array_equal(E[torch.from_numpy(idx[:, 0]).long()].numpy(), want.numpy())
+        np.testing.assert_array_equal(plan.pos[off:off + T], p.pos.numpy())
+        off += T
+    inp = m.inputs(task_list=["len"] * 3, phns_list=phns, proms_list=proms, lang_list=langs, len_list=seqs)
+    assert [n for n, _ in inp[0]] == ["task", "phn", "lang", "quant_level", "prom", "len", "classifier_level"]
+    assert inp[0][-1] == ("classifier_level", "len")
+    again = m.plan_from_inputs(inp)
+    assert np.array_equal(again.idx, plan.idx) and np.array_equal(again.pos, plan.pos) and again.head == plan.head
+    # base.py:679-681: with resps instead of len tokens the digits of the frame count are encoded, 0-led and 10-ended
+    enc = m.inputs(task_list=["len"], phns_list=phns[:1], proms_list=proms[:1], lang_list=langs[:1], resps_list=[torch.zeros(137, 8)])
+    assert dict((n, v) for n, v in enc[0] if n != "task")["len"].tolist() == [0, 1, 3, 7, 10]
+    # a model without the capability has no len head and refuses the task (base.py:654-655)
+    plain = host_model()
+    with pytest.raises(Exception, match="len"):
+        plain.plan(phns, langs, proms, [None] * 3, 0, task="len", len_list=seqs)

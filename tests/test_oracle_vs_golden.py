@@ -160,6 +160,21 @@ def test_tiny_narlen():
     _narlen("tiny", "tiny_narlen")
 
 
+@pytest.mark.parametrize("name", ["tiny_len", "tiny_len_stop"])
+def test_tiny_len_task(name):
+    """Duration prediction (task ``len``): digits, the reference's keep-appending-after-stop quirk, per-step logits."""
+    z = load_golden(name)
+    phns, proms, langs = golden_inputs(z)
+    o = make_oracle("tiny_len", weight_seed=int(z["weight_seed"]))
+    lens, kept, _ = o.predict_len(phns, proms, langs, return_logits=True)
+    assert lens == [int(x) for x in z["lens"]]
+    assert len(kept) == int(z["n_steps"])
+    for n, k in enumerate(kept):
+        assert_close(k, z[f"logits_step{n}"], 5e-5, 5e-5)
+    if name == "tiny_len":        # utterances stop at different steps; digits after a stop token are kept
+        assert len({int(x) for x in z["lens"]}) > 1 and int(z["n_steps"]) == 10
+
+
 def test_full_b1_configs0():
     """BASELINE.json configs[0]: repo-default model, data/qnt.enc prompt, greedy AR + NAR."""
     _ar_nar("full", "full_b1")

@@ -136,6 +136,13 @@ def tiny_model(dim=256, heads=4, layers=2) -> Model:
     return m
 
 
+def tiny_len_model(**kw) -> Model:
+    """``tiny_model`` with the ``len`` capability: adds the 11-token duration head (base.py:404-406)."""
+    m = tiny_model(**kw)
+    m.capabilities = ["ar", "nar", "len"]
+    return m
+
+
 @dataclass
 class Inference:
     # vall_e/config.py:849-862

@@ -2,8 +2,8 @@
 
 Mirrors ``vall_e.inference.TTS`` (reference inference.py:37-597) for what sits on the hot path:
 ``batched_inference`` sorts utterances by ``len(text) + 1 + len(prompt) + 1`` (inference.py:288-293),
-cuts chunks of ``batch_size`` (:296-311) and runs AR then NAR, or (NAR-len) demasking then NAR,
-per chunk (:326-346).  The reference's text front end (phonemizer) and codec (EnCodec/Vocos) are
+cuts chunks of ``batch_size`` (:296-311) and runs AR then NAR, or (NAR-len) duration prediction
+(task ``len``, unless ``len_list`` is given), demasking then NAR, per chunk (:326-346).  The reference's text front end (phonemizer) and codec (EnCodec/Vocos) are
 out of scope: texts are phoneme-id tensors, references are ``(P, 8)`` code tensors, and the
 result is the list of ``(R, 8)`` code tensors the reference would hand to ``qnt.decode``
 (inference.py:350-355), in the caller's order.
@@ -135,6 +135,7 @@ class TTS:
         modality = self.modality(sampling_kwargs.pop("modality", "auto"))
         for k in ("input_prompt_length", "seed", "tqdm", "use_lora", "dtype", "amp"):
             sampling_kwargs.pop(k, None)
+        duration_padding = sampling_kwargs.pop("duration_padding", 1.05)
         n = len(texts)
         references = list(references) if references else [None] * n
         languages = list(languages) if languages else [torch.tensor([0], dtype=torch.uint8)] * n
@@ -145,9 +146,12 @@ class TTS:
             kw = dict(task_list=["tts"] * len(idx), phns_list=[texts[i] for i in idx],
                       proms_list=[references[i] for i in idx], lang_list=[languages[i] for i in idx])
             if modality == "nar-len":
-                if len_list is None:
-                    raise NotImplementedError("the `len` task (duration prediction) is not built: pass len_list")
-                resps = self.model(**kw, len_list=[len_list[i] for i in idx], **sampling_kwargs)
+                if len_list is not None:
+                    lens = [len_list[i] for i in idx]
+                else:                                                            # inference.py:328-332
+                    lens = self.model(**{**kw, "task_list": ["len"] * len(idx)}, max_duration=5)
+                    lens = [int(l * duration_padding) for l in lens]
+                resps = self.model(**kw, len_list=lens, **sampling_kwargs)
             else:
                 resps = self.model(**kw, **sampling_kwargs)
                 resps = self.model(**kw, resps_list=resps, **sampling_kwargs)

@@ -69,8 +69,8 @@ class AR_NAR(Base):
                 len_list=None, text_list=None, training=None, disable_tqdm=False, use_lora=None, **sampling_kwargs):
         if text_list is not None or tone_list is not None:
             raise NotImplementedError("raw-text / tone inputs are outside the built path")
-        if task_list is not None and any(t != "tts" for t in task_list):
-            raise NotImplementedError(f"tasks {sorted(set(task_list))}: only 'tts' (AR, NAR, NAR-len) is built")
+        if task_list is not None and any(t not in ("tts", "len") for t in task_list):
+            raise NotImplementedError(f"tasks {sorted(set(task_list))}: only 'tts' (AR, NAR, NAR-len) and 'len' are built")
         if training:
             raise NotImplementedError("training is out of scope")
         if training is None and phns_list is not None and resps_list is not None:
@@ -85,10 +85,43 @@ class AR_NAR(Base):
 
     __call__ = forward
 
+    # ----------------------------------------------------------------------------------- len
+    def forward_len(self, phns_list, proms_list=None, lang_list=None, return_logits=False):
+        """Duration prediction, ar_nar.py:640-692: at most 10 greedy steps over the 11-token ``len`` head,
+        every utterance seeded with digit 0.  Utterances that already produced the stop token (10) keep
+        being extended until all have, and the integer drops stop tokens only -- both as in the reference.
+        Each step is one dense pass over phn|lang|quant_level|prom|len (a few hundred rows per utterance)."""
+        self._prepare()
+        B = len(phns_list)
+        stop = 10
+        V = self.cls_tokens[self.cls_names.index("len")] if "len" in self.cls_names else 0
+        seqs = [np.zeros(1, dtype=np.int64) for _ in range(B)]
+        stopped = np.zeros(B, dtype=bool)
+        greedy = L.SampleParams(0.0, -100, 1.0, 0.0, 0.0, 1.0, 0.0, 0.0, stop, 1, 0, 0)
+        row_off = np.arange(B + 1, dtype=np.int32)
+        kept = []
+        for _ in range(10):
+            plan = self.plan(phns_list, lang_list, proms_list, [None] * B, 0, task="len", len_list=seqs)
+            rows, _ = self.tail_rows(plan, [1] * B)
+            logits = self.forward_dense(plan, rows)
+            if return_logits:
+                kept.append(logits[:, :V].clone())
+            ids, _ = self.sample_rows(logits, V, row_off, None, nar_mode=0, params=greedy)
+            toks = np.minimum(ids.cpu().numpy().astype(np.int64), stop)         # ar_nar.py:675-677
+            stopped |= toks == stop
+            seqs = [np.concatenate((s, toks[i:i + 1])) for i, s in enumerate(seqs)]
+            if stopped.all():
+                break
+        out = [int("".join(str(int(t)) for t in s if t != stop)) for s in seqs]
+        return (out, kept) if return_logits else out
+
     # ------------------------------------------------------------------------------------ AR
     def forward_ar(self, task_list=None, phns_list=None, proms_list=None, resps_list=None, lang_list=None,
                    disable_tqdm=False, use_lora=None, **sampling_kwargs):
-        """Level-0 autoregressive loop, ar_nar.py:588-890 (tts task)."""
+        """Level-0 autoregressive loop, ar_nar.py:588-890 (tts task); duration prediction for the len task."""
+        if task_list is not None and task_list[0] == "len":                     # ar_nar.py:640
+            return self.forward_len(phns_list=phns_list, proms_list=proms_list, lang_list=lang_list,
+                                    return_logits=sampling_kwargs.get("return_logits", False))
         self._prepare()
         lib = L.load()
         kw = convert_kwargs(dict(sampling_kwargs), "ar_")

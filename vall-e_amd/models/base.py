@@ -228,17 +228,20 @@ class Base:
     def inputs(self, phns_list=None, text_list=None, proms_list=None, resps_list=None, lang_list=None, tone_list=None,
                len_list=None, task_list=None, time_list=None, quant_levels=None):
         """The reference's per-utterance list of (name, value) tuples for the TTS layout (base.py:560-649):
-        task, phn, lang, quant_level, prom, resp, classifier_level -- accepted by ``forward_super``."""
-        if text_list is not None or tone_list is not None or len_list is not None:
-            raise NotImplementedError("raw-text / tone / len inputs are outside the built path")
+        task, phn, lang, quant_level, prom, resp, classifier_level -- and for the ``len`` task (base.py:652-683):
+        task, phn, lang, quant_level, prom, len, classifier_level -- accepted by ``forward_super``."""
+        if text_list is not None or tone_list is not None:
+            raise NotImplementedError("raw-text / tone inputs are outside the built path")
         first = next(l for l in (phns_list, proms_list, resps_list) if l)
         B = len(first)
         out = [[] for _ in range(B)]
         for i in range(B):
             q = int(quant_levels[i]) if quant_levels is not None else 0
             task = task_list[i] if task_list is not None else "tts"
-            if task != "tts":
-                raise NotImplementedError(f"task {task!r}: only 'tts' is built")
+            if task not in ("tts", "len"):
+                raise NotImplementedError(f"task {task!r}: only 'tts' and 'len' are built")
+            if task == "tts" and len_list is not None:
+                raise NotImplementedError("len inputs belong to the 'len' task")
             timestep = time_list[i] if time_list is not None else None
             out[i].append(("task", task))
             if phns_list is not None and phns_list[i] is not None:
@@ -249,6 +252,16 @@ class Base:
             level = "AR:0:0" if q == 0 else f"NAR:{q-1}:{q}"
             if proms_list is not None and proms_list[i] is not None:
                 out[i].append(("prom", proms_list[i]))
+            if task == "len":
+                if "len" not in self.cls_names:                              # base.py:654-655
+                    raise Exception("Requesting task `len` but corresponding embedding is not defined.")
+                if len_list is not None and len_list[i] is not None:
+                    out[i].append(("len", len_list[i]))
+                elif resps_list is not None and resps_list[i] is not None:   # base.py:679-681: digits of the frame count
+                    digits = [0] + [int(c) for c in str(int(resps_list[i].shape[0]))] + [10]
+                    out[i].append(("len", torch.tensor(digits, dtype=torch.int16)))
+                out[i].append(("classifier_level", "len"))
+                continue
             if timestep is not None:
                 level = "NAR:0:0"                                           # base.py:628
             if resps_list is not None and resps_list[i] is not None:
@@ -258,23 +271,33 @@ class Base:
 
     def plan_from_inputs(self, inputs):
         """``inputs()`` tuples -> Plan.  One classifier level per batch (one head per dense pass)."""
-        col = {k: [dict((n, v) for n, v in item if n != "task").get(k) for item in inputs] for k in ("phn", "lang", "prom", "resp")}
+        col = {k: [dict((n, v) for n, v in item if n != "task").get(k) for item in inputs] for k in ("phn", "lang", "prom", "resp", "len")}
         levels = {dict(item)["classifier_level"] for item in inputs}
         qs = {int(dict(item)["quant_level"][0]) for item in inputs}
         if len(levels) != 1 or len(qs) != 1:
             raise NotImplementedError("one classifier level per batch")
         level, q = levels.pop(), qs.pop()
+        if level == "len":
+            return self.plan(col["phn"] if any(p is not None for p in col["phn"]) else None,
+                             col["lang"] if any(p is not None for p in col["lang"]) else None,
+                             col["prom"] if any(p is not None for p in col["prom"]) else None,
+                             [None] * len(inputs), q, task="len", len_list=col["len"])
         resps = col["resp"] if any(r is not None for r in col["resp"]) else [None] * len(inputs)
         return self.plan(col["phn"] if any(p is not None for p in col["phn"]) else None,
                          col["lang"] if any(p is not None for p in col["lang"]) else None,
                          col["prom"] if any(p is not None for p in col["prom"]) else None,
                          resps, q, timestep=(level == "NAR:0:0"))
 
-    def plan(self, phns_list, lang_list, proms_list, resps_list, quant_level, *, timestep=False) -> Plan:
+    def plan(self, phns_list, lang_list, proms_list, resps_list, quant_level, *, timestep=False, task="tts",
+             len_list=None) -> Plan:
         """TTS layout phn, lang, quant_level, prom, resp with a ``sep`` row between segments
         (base.py:603-649, :101-110); classifier level per base.py:618/:628; position ids restart per
-        segment, non-output segments count their trailing sep (base.py:984)."""
+        segment, non-output segments count their trailing sep (base.py:984).  task "len" (base.py:652-683):
+        the length digits (``len_list``) stand where resp does and the head is ``len``."""
         off = self._off
+        out_kind = "len" if task == "len" else "resp"                                # task_outputs, base.py:53-61
+        if task == "len" and "len" not in self.cls_names:
+            raise Exception("Requesting task `len` but corresponding embedding is not defined.")
         B = len(resps_list)
         q = quant_level
         idx_all, pos_all, lens, out_len = [], [], [], []
@@ -306,7 +329,9 @@ class Base:
                     for l in range(n):
                         r[:, l] = off[f"prom{l}"] + prom[:, l]
                     segs.append(("prom", r))
-            resp = resps_list[i]
+            if task == "len" and len_list is not None and len_list[i] is not None:
+                segs.append(("len", rows1(off["len"], _np(len_list[i]))))
+            resp = resps_list[i] if task != "len" else None
             if resp is not None:
                 resp = _np(resp)
                 if timestep:                                                          # NAR-len: base.py:869-874
@@ -327,14 +352,16 @@ class Base:
                 if j:
                     parts.append(sep_row)
                 parts.append(r)
-                pos.append(np.arange(r.shape[0] + (0 if kind == "resp" else 1), dtype=np.int32))
+                pos.append(np.arange(r.shape[0] + (0 if kind == out_kind else 1), dtype=np.int32))
             idx = np.concatenate(parts)
             pos = np.concatenate(pos)[: idx.shape[0]]
             if self.unified_position_ids:
                 pos = np.arange(idx.shape[0], dtype=np.int32)
             idx_all.append(idx), pos_all.append(pos), lens.append(idx.shape[0])
-            out_len.append(segs[-1][1].shape[0] if segs[-1][0] == "resp" else 0)
+            out_len.append(segs[-1][1].shape[0] if segs[-1][0] == out_kind else 0)
         head = "NAR:0:0" if timestep else ("AR:0:0" if q == 0 else f"NAR:{q-1}:{q}")
+        if task == "len":
+            head = "len"
         return Plan(np.concatenate(idx_all), np.concatenate(pos_all), lens, out_len, self.cls_names.index(head))
 
     # ------------------------------------------------------------------------ dense forward
