@@ -18,6 +18,7 @@ Scenarios (names = file stems under tests/golden/):
   tiny_sampling     tiny model: greedy AR under rep-pen / length-pen / top-k / top-p, stop-token path
   tiny_cfg          tiny model: AR + NAR with cfg_strength > 0
   tiny_narlen       tiny model: NAR-len demasking (max_steps 6) + NAR levels
+  tiny_noncausal    tiny model with noncausal_masks=True: tiny_nc_ar_nar (AR + NAR levels), tiny_nc_narlen
   tiny_len          tiny model with the `len` capability: duration prediction (task "len"), per-step logits
   full_b1           BASELINE configs[0]: full model, qnt.enc prompt, 19 phonemes, AR 24 + NAR
   full_b3           full model, ragged B=3, AR 12 + NAR
@@ -93,8 +94,11 @@ def get_ref_model(kind, dtype=torch.float32, **synth_kw):
     key = (kind, dtype, tuple(sorted(synth_kw.items())))
     if key in _models:
         return _models[key]
-    mcfg = {"full": vcfg.repo_default_model, "tiny": vcfg.tiny_model, "tiny_len": vcfg.tiny_len_model}[kind]()
-    model = rh.build_reference_model(size=mcfg.size, capabilities=list(mcfg.capabilities))
+    mcfg = {"full": vcfg.repo_default_model, "tiny": vcfg.tiny_model, "tiny_len": vcfg.tiny_len_model,
+            "tiny_nc": vcfg.tiny_nc_model}[kind]()
+    model = rh.build_reference_model(size=mcfg.size, capabilities=list(mcfg.capabilities),
+                                     noncausal_masks=mcfg.experimental.noncausal_masks)
+    assert model.noncausal_masks == mcfg.experimental.noncausal_masks
     synth_kw = dict(synth_kw)
     sd = synth_state_dict(mcfg, synth_kw.pop("weight_seed", WEIGHT_SEED), **synth_kw)
     missing = model.load_state_dict(sd, strict=True)
@@ -437,6 +441,15 @@ def scen_tiny_len():
         save(name, **d)
 
 
+def scen_tiny_noncausal():
+    """``noncausal_masks=True`` (the published ar+nar-len checkpoint's switch): AR stays causal, NAR levels and the
+    NAR-len demasking attend in both directions."""
+    mk = lambda s: synth_batch(s, 3, n_phn=12, n_prom=20, ragged=True)
+    ar_nar_scenario("tiny_nc_ar_nar", "tiny_nc", mk, 81, steps=20)
+    phns, proms, langs = synth_batch(83, 2, n_phn=10, n_prom=16, ragged=True)
+    narlen_scenario("tiny_nc_narlen", "tiny_nc", phns, proms, langs, lens=[17, 23], max_steps=5)
+
+
 def scen_full_b1():
     ref = rh.load_reference()
     phns, proms, langs = qnt_inputs()
@@ -487,6 +500,7 @@ SCENARIOS = {
     "tiny_cfg": scen_tiny_cfg,
     "tiny_narlen": scen_tiny_narlen,
     "tiny_len": scen_tiny_len,
+    "tiny_noncausal": scen_tiny_noncausal,
     "full_b1": scen_full_b1,
     "full_b3": scen_full_b3,
     "full_narlen": scen_full_narlen,

@@ -299,10 +299,12 @@ class Oracle:
         rot = torch.cat((-x[..., h:], x[..., :h]), dim=-1)
         return x * cos + rot * sin
 
-    def stack(self, x, pos, lens, kv=None, layer_probe=None):
+    def stack(self, x, pos, lens, kv=None, layer_probe=None, causal=None):
         """x: packed (sum(lens), d); pos: packed position ids; lens: rows per utterance.
         kv: optional list (per layer) of per-utterance [K, V] caches that are appended to
-        (KV-cache mode); attention then runs each new row against cache + new rows."""
+        (KV-cache mode); attention then runs each new row against cache + new rows.
+        causal: per-utterance flags (default all True); False = every row sees every row of its own
+        utterance (``noncausal_masks``, arch/llama.py:594-614, :837-841)."""
         cos, sin = self.rope(pos)
         cos, sin = cos[:, None, :], sin[:, None, :]
         offs = [0]
@@ -329,7 +331,9 @@ class Oracle:
                         vb = torch.cat([kv[l][b][1], vb], dim=1)
                     kv[l][b] = [kb, vb]
                 Tk = kb.shape[1]
-                mask = torch.ones(n, Tk, dtype=torch.bool).tril(diagonal=past)
+                mask = torch.ones(n, Tk, dtype=torch.bool)
+                if causal is None or causal[b]:
+                    mask = mask.tril(diagonal=past)
                 att = (qb @ kb.transpose(1, 2)) * scale
                 att = att.masked_fill(~mask, float("-inf"))
                 att = torch.softmax(att.float(), dim=-1).to(qb.dtype)
@@ -351,11 +355,18 @@ class Oracle:
         k = self.cls_names.index(name)
         return F.linear(x, self.w[f"classifiers.proj.{k}.weight"], self.w.get(f"classifiers.proj.{k}.bias"))
 
+    def is_causal(self, head):
+        """base.py:1230-1233: with ``noncausal_masks`` only the AR / len / phn levels keep the causal mask."""
+        if not self.cfg.experimental.noncausal_masks:
+            return True
+        return head in ("phn", "len") or head.startswith("AR:")
+
     # -- one forward over a batch of plans: list of (T_i, V) logits (Base.forward) --------------
     def forward(self, plans, rows=None, probe=None):
         xs = [self.embed_sequence(p) for p in plans]
         lens = [x.shape[0] for x in xs]
-        hid = self.stack(torch.cat(xs), torch.cat([p.pos for p in plans]), lens, layer_probe=probe)
+        hid = self.stack(torch.cat(xs), torch.cat([p.pos for p in plans]), lens, layer_probe=probe,
+                         causal=[self.is_causal(p.head) for p in plans])
         out, o = [], 0
         for i, (p, n) in enumerate(zip(plans, lens)):
             hi = hid[o:o + n]

@@ -45,7 +45,8 @@ _cache = {}
 
 def model_cfg(kind):
     from vall_e_amd import config as vcfg
-    return {"full": vcfg.repo_default_model, "tiny": vcfg.tiny_model, "tiny_len": vcfg.tiny_len_model}[kind]()
+    return {"full": vcfg.repo_default_model, "tiny": vcfg.tiny_model, "tiny_len": vcfg.tiny_len_model,
+            "tiny_nc": vcfg.tiny_nc_model}[kind]()
 
 
 def synth_weights(kind, **kw):

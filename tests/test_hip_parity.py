@@ -288,6 +288,22 @@ def test_tts_narlen_predicts_duration(gpu_device):
         np.testing.assert_array_equal(got[i].cpu().numpy(), want[j].numpy())
 
 
+def test_tiny_noncausal_masks_codes_identical(gpu_device):
+    """noncausal_masks=True (the published ar+nar-len checkpoint's switch, base.py:1230-1233): AR codes, NAR codes
+    and NAR-len codes equal the reference's; bf16 (flash kernel, causal=0) agrees with the bf16 oracle's logits."""
+    _ar_nar("tiny_nc", "tiny_nc_ar_nar")
+    _narlen("tiny_nc", "tiny_nc_narlen")
+    z = load_golden("tiny_nc_ar_nar")
+    phns, proms, langs = golden_inputs(z)
+    resps = [torch.from_numpy(z[f"nar_codes_{b}"][:, :3].astype(np.int64)) for b in range(len(phns))]
+    m, o = hip_model("tiny_nc", torch.bfloat16), oracle("tiny_nc", torch.bfloat16)
+    got = m.forward_super(dict(phns_list=phns, lang_list=langs, proms_list=proms, resps_list=resps), quant_levels=[3] * len(phns)).logits
+    import valle_oracle as vo
+    want = o.forward([vo.plan_sequence(phns[i], langs[i], proms[i], resps[i], 3) for i in range(len(phns))])
+    for g, w in zip(got, want):
+        assert rel_l2(g, w.float()) < 4e-2
+
+
 def test_full_bf16_logits_within_tolerance(gpu_device):
     """bf16 tolerance (stated): rel-L2 <= 4e-2 against the reference's bf16 logits; the reference's
     own bf16 run sits 2.2e-2 from its fp32 run on these rows (see test_oracle_vs_golden)."""

@@ -151,6 +151,11 @@ def _narlen(kind, name):
     z = load_golden(name)
     phns, proms, langs = golden_inputs(z)
     o = make_oracle(kind)
+    if "level0_first_step_logits_0" in z:
+        n0 = int(z["lens"][0])
+        plans = [vo.plan_sequence(phns[i], langs[i], proms[i], torch.full((int(z["lens"][i]),), o.mask_token), 0, timestep=True)
+                 for i in range(len(phns))]
+        assert_close(o.forward(plans, rows=[int(x) for x in z["lens"]])[0], z["level0_first_step_logits_0"][-n0:], 5e-4, 5e-4)
     full = o.nar_len(phns, proms, langs, [int(x) for x in z["lens"]], max_steps=int(z["max_steps"]), temperature=0.0)
     for b in range(len(phns)):
         np.testing.assert_array_equal(full[b].numpy(), z[f"codes_{b}"])
@@ -173,6 +178,19 @@ def test_tiny_len_task(name):
         assert_close(k, z[f"logits_step{n}"], 5e-5, 5e-5)
     if name == "tiny_len":        # utterances stop at different steps; digits after a stop token are kept
         assert len({int(x) for x in z["lens"]}) > 1 and int(z["n_steps"]) == 10
+
+
+def test_tiny_noncausal_masks():
+    """noncausal_masks=True (base.py:1230-1233): AR causal, NAR levels and NAR-len demasking bidirectional."""
+    _ar_nar("tiny_nc", "tiny_nc_ar_nar")
+    _narlen("tiny_nc", "tiny_nc_narlen")
+    # the switch matters: the causal model gives other NAR codes on the same inputs
+    z = load_golden("tiny_nc_ar_nar")
+    phns, proms, langs = golden_inputs(z)
+    causal = make_oracle("tiny_len")
+    codes = [torch.from_numpy(z[f"ar_codes_{b}"].astype(np.int64)) for b in range(len(phns))]
+    other = causal.nar(phns, proms, langs, codes, temperature=0.0)
+    assert any((other[b].numpy() != z[f"nar_codes_{b}"]).any() for b in range(len(phns)))
 
 
 def test_full_b1_configs0():

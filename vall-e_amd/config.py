@@ -143,6 +143,14 @@ def tiny_len_model(**kw) -> Model:
     return m
 
 
+def tiny_nc_model(**kw) -> Model:
+    """Tiny sibling of the published ``ar+nar-len-llama-8`` switches: ``len`` head and ``noncausal_masks``
+    (NAR levels attend in both directions, base.py:1230-1233)."""
+    m = tiny_len_model(**kw)
+    m.experimental.noncausal_masks = True
+    return m
+
+
 @dataclass
 class Inference:
     # vall_e/config.py:849-862

@@ -404,9 +404,11 @@ class Base:
         hidden = torch.empty((n_out, self.d_model), dtype=self.dtype, device=self.device) if want_hidden else None
         need = lib.valle_dense_workspace_bytes(self._handle, plan.M, n_out)
         ws = self._workspace(need)
-        causal = 1  # noncausal_masks=False: every pass is causal (base.py:1233)
-        if self.noncausal_masks:
-            raise NotImplementedError("noncausal_masks=True")
+        # base.py:1230-1233: with noncausal_masks the NAR levels (NAR:q-1:q, NAR:0:0) attend in both directions
+        level = self.cls_names[plan.head]
+        causal = 1 if (not self.noncausal_masks or level in ("phn", "len") or level.startswith("AR:")) else 0
+        if not causal and cache is not None:
+            raise ValueError("a KV cache only makes sense for a causal pass")
         if cache is None:
             kc = vc = slot = pos0 = None
             cache_T, stride = 0, 0
