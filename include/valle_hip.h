@@ -117,11 +117,21 @@ typedef struct {
     int   rep_pen_passes;           /* 1; 2 reproduces NAR-len's second in-place pass        */
     uint64_t seed;                  /* Philox seed for temperature > 0                       */
     uint64_t offset;                /* Philox offset (advance per call)                      */
+    /* dynamic temperature (samplers.py:128-141), on when |temperature - min_temperature| >= 0.001
+     * (base.py:1389): the reference computes it in Python doubles, hence the double copies        */
+    double temperature64;
+    double min_temperature64;       /* set equal to temperature64 for "off" (base.py:1313-1314)     */
+    /* DRY (samplers.py:248-275), on when dry_multiplier > 0 and the row has previous tokens        */
+    double dry_multiplier;
+    double dry_base;
+    int    dry_allowed_length;      /* >= 2 makes the reference's loop a no-op; kept for fidelity   */
+    int    reserved;
 } valle_sample_params;
 
 /* Sampler chain on fp32 logits [rows][ld] (first `vocab` columns valid): repetition penalty
  * (samplers.py:16-50) -> length penalty (:56-61, AR rows) -> min-p (:74-90) -> top-k/top-p
- * (:93-125) -> /temperature -> top-n-sigma (:164-172) -> argmax or categorical
+ * (:93-125) -> dynamic temperature (:128-141) or /temperature -> top-n-sigma (:164-172) -> DRY
+ * (:248-275) -> argmax or categorical
  * (base.py:1419-1422) -> score = softmax(processed)[token] (base.py:1425-1428).
  * Row r belongs to utterance row_item[r]; its previous tokens are prev[prev_off[i] ..
  * prev_off[i] + prev_len[i]).  nar_mode != 0: row r (row_in_item[r]) is penalised only by

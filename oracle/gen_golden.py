@@ -13,6 +13,7 @@ Scenarios (names = file stems under tests/golden/):
                     with an opcode scanner that executes nothing (the file is a pickled
                     object array; numpy's safe loader refuses it), + its phoneme ids
   samplers_kat      known-answer vectors for vall_e/samplers.py processors
+  samplers_kat2     dynamic temperature + DRY known answers, Base.sample end to end with both on
   tiny_fwd          tiny model (d=256,h=4,L=2): embeddings, position ids, hidden states, logits
   tiny_ar_nar       tiny model, ragged B=3: greedy AR + 7 NAR levels, margins
   tiny_sampling     tiny model: greedy AR under rep-pen / length-pen / top-k / top-p, stop-token path
@@ -226,6 +227,39 @@ def scen_samplers():
     r = S.cfg_logits([p.clone() for p in pos], [n.clone() for n in neg], strength=2.0, lens=[5, 9], rescale=0.0)
     out["cfg_norescale_0"], out["cfg_norescale_1"] = r
     save("samplers_kat", **out)
+
+
+def scen_samplers2():
+    """Known answers for the two remaining deterministic processors, samplers.py:128-141 (dynamic temperature)
+    and :248-275 (DRY), plus Base.sample end to end with them switched on (greedy pick, so no RNG)."""
+    ref = rh.load_reference()
+    S = ref.samplers
+    model, _ = get_ref_model("tiny")
+    g = torch.Generator().manual_seed(17)
+    out = {}
+    logits = torch.randn(5, 1025, generator=g) * 2.0
+    logits[1] *= 3.0                                    # a peaked row: p_max near 1 -> temperature near the minimum
+    logits[2] *= 0.05                                   # a flat row
+    out["logits"] = logits.clone()
+    out["dyn_a"] = S.dynamic_temperature(logits.clone(), temperature=1.0, min_temperature=0.2)
+    out["dyn_b"] = S.dynamic_temperature(logits.clone(), temperature=0.0, min_temperature=0.6)
+    filt = S.top_k_top_p_filtering(logits.clone(), top_k=12, top_p=1.0)
+    out["dyn_after_topk"] = S.dynamic_temperature(filt, temperature=0.9, min_temperature=0.3)
+    # DRY: a sequence whose tail repeats earlier material, on tensor tokens exactly as Base.sample passes them
+    prev = torch.tensor([5, 9, 7, 5, 9, 7, 5, 9, 300, 7, 5, 9], dtype=torch.int16)
+    out["dry_prev"] = prev
+    for tag, al in (("al2", 2), ("al1", 1), ("al0", 0)):
+        out[f"dry_{tag}"] = S.dry_sampling(logits[:1].clone(), previous=prev, factor=0.8, base=1.75, allowed_length=al)
+    out["dry_nar_al1"] = S.dry_sampling(logits.clone(), previous=prev[:5], factor=0.5, base=2.0, allowed_length=1)
+    # Base.sample end to end: AR row (prev longer than 1) and NAR rows (len(prev) == rows)
+    with torch.inference_mode():
+        r = model.sample(logits=[logits[:1].clone()], prev_list=[prev.clone()], temperature=0.0, min_temperature=0.5,
+                         dry_multiplier=0.8, dry_allowed_length=1, repetition_penalty=1.2, top_no=0.0)
+        out["sample_ar_ids"], out["sample_ar_scores"], out["sample_ar_logits"] = r.ids[0], r.scores[0], r.logits[0]
+        r = model.sample(logits=[logits.clone()], prev_list=[prev[:5].clone()], quant_levels=[1], temperature=0.0,
+                         min_temperature=0.4, dry_multiplier=0.5, dry_base=2.0, dry_allowed_length=1)
+        out["sample_nar_ids"], out["sample_nar_scores"], out["sample_nar_logits"] = r.ids[0], r.scores[0], r.logits[0]
+    save("samplers_kat2", **out)
 
 
 def first_forward_probe(model, ref, phns, proms, langs, rows):
@@ -494,6 +528,7 @@ def scen_full_bf16():
 SCENARIOS = {
     "qnt_enc_prompt": scen_qnt_enc,
     "samplers_kat": scen_samplers,
+    "samplers2": scen_samplers2,
     "tiny_fwd": scen_tiny_fwd,
     "tiny_ar_nar": scen_tiny_ar_nar,
     "tiny_sampling": scen_tiny_sampling,

@@ -150,6 +150,48 @@ def top_n_sigma(logits, n=1.0):
     return torch.where(logits >= m - n * sd, logits, torch.full_like(logits, -float("inf")))
 
 
+def dynamic_temperature(logits, temperature=1.0, min_temperature=0.0, k=10, center=0.5):
+    """samplers.py:128-141.  Per row: p_max = 1 / sum(exp(logit - max)) (the differences are fp32, the
+    exponentials and their sum Python doubles), temperature slides from ``temperature`` (flat row) to
+    ``min_temperature`` (peaked row) on a sigmoid of p_max; the row is divided by it in place."""
+    for i in range(logits.shape[0]):
+        diffs = (logits[i] - torch.max(logits[i])).tolist()
+        sum_exp = 0.0
+        for dlt in diffs:
+            sum_exp += math.exp(dlt)
+        p_max = 1.0 / sum_exp
+        t = temperature - (temperature - min_temperature) / (1 + math.exp(-k * (p_max - center)))
+        logits[i] /= t
+    return logits
+
+
+def dry_sampling(logits, previous=None, factor=0.0, base=1.75, allowed_length=2):
+    """samplers.py:248-275 AS IT RUNS on tensor tokens: the ``lengths`` dict is keyed by 0-dim tensors, which
+    hash by identity, so every POSITION of ``previous`` keeps its own entry (no per-token max), in position
+    order; the penalty loop ``break``s at the first entry shorter than ``allowed_length`` -- position 0 always
+    has length 1, so with the default allowed_length=2 the processor changes nothing."""
+    if factor == 0.0 or previous is None:
+        return logits
+    prev = [int(t) for t in previous]
+    n = len(prev)
+    entries = []
+    for i in range(n):
+        length = 1
+        while length < max(allowed_length, 50):
+            j = i - length
+            if j < 0:
+                break
+            if prev[j] != prev[n - length - 1]:
+                break
+            length += 1
+        entries.append((prev[i], length))
+    for tok, length in entries:
+        if length < allowed_length:
+            break
+        logits[:, tok] -= factor * base ** (length - allowed_length)
+    return logits
+
+
 def cfg_combine(pos_logits, null_logits, strength, lens, rescale=0.0):
     """samplers.py:177-191: in place on the last ``len`` rows of each positive logit tensor.
     For 2-D logits ``dims=()`` makes std a GLOBAL unbiased std over rows x vocab."""
@@ -165,8 +207,9 @@ def cfg_combine(pos_logits, null_logits, strength, lens, rescale=0.0):
 
 def sample(logits, prev_list=None, quant_levels=None, *, causal_size=1, stop_token=1024, generator=None,
            temperature=1.0, min_temperature=-1.0, top_k=-100, top_p=1.0, min_p=0.0,
-           repetition_penalty=1.0, repetition_penalty_decay=0.0, length_penalty=0.0, top_no=1.0, **_unused):
-    """Base.sample (base.py:1280-1430), basic branch (no beam / mirostat / DRY / entropix).
+           repetition_penalty=1.0, repetition_penalty_decay=0.0, length_penalty=0.0, top_no=1.0,
+           dry_multiplier=0.0, dry_base=1.75, dry_allowed_length=2, **_unused):
+    """Base.sample (base.py:1280-1430), basic branch (no beam / mirostat / entropix).
     Returns (ids, processed_logits, scores)."""
     if min_temperature < 0:
         min_temperature = temperature
@@ -185,12 +228,14 @@ def sample(logits, prev_list=None, quant_levels=None, *, causal_size=1, stop_tok
         logits = [min_p_filter(l, min_p) for l in logits]
     if top_k > 0 or top_p < 1.0:
         logits = [top_k_top_p_filter(l, top_k, top_p) for l in logits]
-    if abs(temperature - min_temperature) >= 0.001:
-        raise NotImplementedError("dynamic temperature is outside the restated path")
+    if abs(temperature - min_temperature) >= 0.001:                         # :1389-1390
+        logits = [dynamic_temperature(l, temperature, min_temperature) for l in logits]
     elif temperature > 0.0:
         logits = [l / temperature for l in logits]
     if top_no > 0.0:
         logits = [top_n_sigma(l) for l in logits]
+    if dry_multiplier > 0.0 and prev_list is not None:                       # :1399-1400
+        logits = [dry_sampling(l, p, dry_multiplier, dry_base, dry_allowed_length) for l, p in zip(logits, prev_list)]
     if temperature <= 0.0:
         ids = [l.argmax(dim=-1) for l in logits]
     else:

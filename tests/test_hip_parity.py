@@ -157,6 +157,55 @@ def test_sampler_known_answers(gpu_device):
         torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
 
 
+def test_sampler_dynamic_temperature_and_dry(gpu_device):
+    """valle_sample with dynamic temperature (samplers.py:128-141) and DRY (:248-275) against the reference's own
+    outputs (samplers_kat2): greedy ids identical, score = softmax(processed)[id] within fp32 noise."""
+    m = hip_model("tiny")
+    z = load_golden("samplers_kat2")
+    lg, prev = torch.from_numpy(z["logits"]), torch.from_numpy(z["dry_prev"])
+
+    def run(logits, prev, nar, **kw):
+        rows, V = logits.shape
+        buf = torch.zeros((rows, (V + 7) // 8 * 8), device=gpu_device)
+        buf[:, :V] = logits.to(gpu_device)
+        ids, sc = m.sample_rows(buf, V, np.array([0, rows], dtype=np.int32), [prev] if prev is not None else None, nar,
+                                m.sample_params(**kw))
+        return ids.cpu().numpy(), sc.cpu().numpy()
+
+    def want(name):
+        t = torch.from_numpy(z[name])
+        ids = t.argmax(-1)
+        return ids.numpy(), torch.softmax(t, -1).gather(1, ids[:, None])[:, 0].numpy()
+
+    ids, sc = run(lg, None, 1, top_no=0.0, temperature=0.0, min_temperature=0.6)      # greedy pick, dynamic scale
+    wid, wsc = want("dyn_b")
+    np.testing.assert_array_equal(ids, wid)
+    np.testing.assert_allclose(sc, wsc, rtol=1e-4)
+    for tag, al in (("al2", 2), ("al1", 1), ("al0", 0)):
+        ids, sc = run(lg[:1], prev, 0, temperature=0.0, top_no=0.0, dry_multiplier=0.8, dry_base=1.75, dry_allowed_length=al)
+        wid, wsc = want(f"dry_{tag}")
+        np.testing.assert_array_equal(ids, wid, err_msg=tag)
+        np.testing.assert_allclose(sc, wsc, rtol=1e-4, err_msg=tag)
+    ids, sc = run(lg, prev[:5], 1, temperature=0.0, top_no=0.0, dry_multiplier=0.5, dry_base=2.0, dry_allowed_length=1)
+    wid, wsc = want("dry_nar_al1")
+    np.testing.assert_array_equal(ids, wid)
+    np.testing.assert_allclose(sc, wsc, rtol=1e-4)
+    # Base.sample end to end, both processors on (plus rep-pen / default top-n-sigma), as the reference returned it
+    ids, sc = run(lg[:1], prev, 0, temperature=0.0, min_temperature=0.5, dry_multiplier=0.8, dry_allowed_length=1,
+                  repetition_penalty=1.2, top_no=0.0)
+    np.testing.assert_array_equal(ids, z["sample_ar_ids"])
+    np.testing.assert_allclose(sc, z["sample_ar_scores"], rtol=1e-4)
+    ids, sc = run(lg, prev[:5], 1, temperature=0.0, min_temperature=0.4, dry_multiplier=0.5, dry_base=2.0, dry_allowed_length=1)
+    np.testing.assert_array_equal(ids, z["sample_nar_ids"])
+    np.testing.assert_allclose(sc, z["sample_nar_scores"], rtol=1e-4)
+    # the dynamic temperature itself: with temperature > 0 the draw is random but the score of the drawn id is
+    # softmax(reference-processed row)[id]
+    for name, kw in [("dyn_a", dict(temperature=1.0, min_temperature=0.2)), ("dyn_after_topk", dict(temperature=0.9, min_temperature=0.3, top_k=12))]:
+        ids, sc = run(lg, None, 1, top_no=0.0, seed=5, **kw)
+        t = torch.softmax(torch.from_numpy(z[name]), -1)
+        np.testing.assert_allclose(sc, t.gather(1, torch.from_numpy(ids).long()[:, None])[:, 0].numpy(), rtol=2e-4, atol=1e-7, err_msg=name)
+
+
 # ---------------------------------------------------------------------------- end to end
 def _probe(kind, name, phns, proms, langs):
     z = load_golden(name)

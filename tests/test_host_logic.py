@@ -98,7 +98,11 @@ def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         m.sample_params(beam_width=4)
     with pytest.raises(NotImplementedError):
-        m.sample_params(temperature=1.0, min_temperature=0.5)
+        m.sample_params(mirostat_tau=3.0)
+    sp = m.sample_params(temperature=1.0, min_temperature=0.5, dry_multiplier=0.8, dry_allowed_length=1)
+    assert (sp.temperature64, sp.min_temperature64, sp.dry_multiplier, sp.dry_allowed_length) == (1.0, 0.5, 0.8, 1)
+    sp = m.sample_params(temperature=0.7, min_temperature=0.7004)       # closer than 0.001: plain temperature (base.py:1389)
+    assert sp.temperature64 == sp.min_temperature64
     with pytest.raises(NotImplementedError):
         m(task_list=["stt"], phns_list=None, resps_list=[torch.zeros(3, 8)])
 

@@ -77,6 +77,27 @@ def _probe(kind, z, phns, proms, langs):
         off += T
 
 
+def test_dynamic_temperature_and_dry_known_answers():
+    """samplers.py:128-141 and :248-275 as the reference runs them (DRY on tensor tokens: per-position entries,
+    no-op at the default allowed_length), bit for bit; Base.sample with both on."""
+    z = load_golden("samplers_kat2")
+    lg, prev = torch.from_numpy(z["logits"]), torch.from_numpy(z["dry_prev"])
+    eq = lambda got, name: np.testing.assert_array_equal(got.numpy(), z[name], err_msg=name)
+    eq(vo.dynamic_temperature(lg.clone(), 1.0, 0.2), "dyn_a")
+    eq(vo.dynamic_temperature(lg.clone(), 0.0, 0.6), "dyn_b")
+    eq(vo.dynamic_temperature(vo.top_k_top_p_filter(lg.clone(), 12, 1.0), 0.9, 0.3), "dyn_after_topk")
+    for tag, al in (("al2", 2), ("al1", 1), ("al0", 0)):
+        eq(vo.dry_sampling(lg[:1].clone(), prev, 0.8, 1.75, al), f"dry_{tag}")
+    eq(vo.dry_sampling(lg.clone(), prev[:5], 0.5, 2.0, 1), "dry_nar_al1")
+    np.testing.assert_array_equal(z["dry_al2"], z["logits"][:1])          # the default allowed_length changes nothing
+    ids, l, sc = vo.sample([lg[:1].clone()], [prev.clone()], temperature=0.0, min_temperature=0.5, dry_multiplier=0.8,
+                           dry_allowed_length=1, repetition_penalty=1.2, top_no=0.0)
+    eq(ids[0], "sample_ar_ids"), eq(l[0], "sample_ar_logits"), eq(sc[0], "sample_ar_scores")
+    ids, l, sc = vo.sample([lg.clone()], [prev[:5].clone()], quant_levels=[1], temperature=0.0, min_temperature=0.4,
+                           dry_multiplier=0.5, dry_base=2.0, dry_allowed_length=1)
+    eq(ids[0], "sample_nar_ids"), eq(l[0], "sample_nar_logits"), eq(sc[0], "sample_nar_scores")
+
+
 def test_tiny_forward_probe():
     z = load_golden("tiny_fwd")
     phns, proms, langs = golden_inputs(z)

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
     __shared__ float skey[SAMP_MAXV];
     __shared__ int sidx[SAMP_MAXV];
     __shared__ float red[SAMP_THREADS / 64];
+    __shared__ double red64[SAMP_THREADS / 64];
     __shared__ int s_flag;
     __shared__ float s_f;
     const int row = blockIdx.x;
@@ -192,8 +193,25 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
         __syncthreads();
     }
     (void)need_sort;
-    // ---- temperature
-    if (a.p.temperature > 0.0f) {
+    // ---- dynamic temperature (samplers.py:128-141) or plain temperature (base.py:1389-1392)
+    if (a.p.temperature64 != a.p.min_temperature64) {
+        float mxr = -INFINITY;
+        for (int v = tid; v < V; v += SAMP_THREADS) mxr = fmaxf(mxr, vals[v]);
+        mxr = block_reduce_max(mxr, red);
+        double se = 0.0;                       // the reference sums Python doubles of exp(fp32 difference)
+        for (int v = tid; v < V; v += SAMP_THREADS) se += exp((double)(vals[v] - mxr));
+        for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) red64[tid >> 6] = se;
+        __syncthreads();
+        se = 0.0;
+        for (int i = 0; i < SAMP_THREADS / 64; ++i) se += red64[i];
+        const double p_max = 1.0 / se;
+        const double T = a.p.temperature64, Tmin = a.p.min_temperature64;
+        const float dyn = (float)(T - (T - Tmin) / (1.0 + exp(-10.0 * (p_max - 0.5))));
+        for (int v = tid; v < V; v += SAMP_THREADS) vals[v] = vals[v] / dyn;
+        __syncthreads();
+    } else if (a.p.temperature > 0.0f) {
         for (int v = tid; v < V; v += SAMP_THREADS) vals[v] = vals[v] / a.p.temperature;
         __syncthreads();
     }
@@ -221,6 +239,28 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
         __syncthreads();
         for (int v = tid; v < V; v += SAMP_THREADS) {
             if (any_bad || !(vals[v] >= thr)) vals[v] = -INFINITY;
+        }
+        __syncthreads();
+    }
+    // ---- DRY (samplers.py:248-275 as it runs: one entry per POSITION of prev, in order; the loop stops at the
+    // first entry shorter than allowed_length, and position 0 always has length 1)
+    if (a.p.dry_multiplier > 0.0 && prev != nullptr && n_prev > 0 && a.p.dry_allowed_length < 2) {
+        const int allowed = a.p.dry_allowed_length;
+        const int cap = allowed > 50 ? allowed : 50;
+        for (int v = tid; v < V; v += SAMP_THREADS) {
+            float x = vals[v];
+            for (int i = 0; i < n_prev; ++i) {
+                if (prev[i] != v) continue;
+                int length = 1;
+                while (length < cap) {
+                    const int j = i - length;
+                    if (j < 0) break;
+                    if (prev[j] != prev[n_prev - length - 1]) break;
+                    ++length;
+                }
+                x = x - (float)(a.p.dry_multiplier * pow(a.p.dry_base, (double)(length - allowed)));
+            }
+            vals[v] = x;
         }
         __syncthreads();
     }

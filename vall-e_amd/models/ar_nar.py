@@ -97,7 +97,7 @@ class AR_NAR(Base):
         V = self.cls_tokens[self.cls_names.index("len")] if "len" in self.cls_names else 0
         seqs = [np.zeros(1, dtype=np.int64) for _ in range(B)]
         stopped = np.zeros(B, dtype=bool)
-        greedy = L.SampleParams(0.0, -100, 1.0, 0.0, 0.0, 1.0, 0.0, 0.0, stop, 1, 0, 0)
+        greedy = self.sample_params(temperature=0.0, top_no=0.0)
         row_off = np.arange(B + 1, dtype=np.int32)
         kept = []
         for _ in range(10):

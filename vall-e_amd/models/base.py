@@ -20,7 +20,7 @@ from ..weights import classifier_layout, state_dict_spec
 Logits = namedtuple("Logits", ["logits", "state", "inputs", "loss", "attentions", "hidden_states"])  # base.py:46
 Sampled = namedtuple("Sampled", ["ids", "logits", "scores", "entropy"])                             # base.py:47
 
-UNSUPPORTED_SAMPLERS = ("beam_width", "mirostat_tau", "mirostat_eta", "dry_multiplier", "entropix_sampling",
+UNSUPPORTED_SAMPLERS = ("beam_width", "mirostat_tau", "mirostat_eta", "entropix_sampling",
                         "refine_on_stop", "input_prompt_prefix", "prefix_silence", "layer_skip")
 
 
@@ -433,7 +433,8 @@ class Base:
     # ----------------------------------------------------------------------------- sampling
     def sample_params(self, *, temperature=1.0, min_temperature=-1.0, top_k=-100, top_p=1.0, min_p=0.0,
                       repetition_penalty=1.0, repetition_penalty_decay=0.0, length_penalty=0.0, top_no=1.0,
-                      rep_pen_passes=1, seed=0, offset=0, **other) -> L.SampleParams:
+                      rep_pen_passes=1, seed=0, offset=0, dry_multiplier=0.0, dry_base=1.75, dry_allowed_length=2,
+                      **other) -> L.SampleParams:
         """Base.sample's kwargs (base.py:1288-1309) -> the C struct.  Samplers outside the built
         chain raise instead of being silently ignored."""
         for k in UNSUPPORTED_SAMPLERS:
@@ -443,11 +444,13 @@ class Base:
             raise NotImplementedError("mirostat / entropix sampling are not built on the HIP path")
         if min_temperature < 0:
             min_temperature = temperature
-        if abs(float(temperature) - float(min_temperature)) >= 0.001:
-            raise NotImplementedError("dynamic temperature is not built on the HIP path")
+        if abs(float(temperature) - float(min_temperature)) < 0.001:          # base.py:1389: dynamic temperature off
+            min_temperature = temperature
         return L.SampleParams(float(temperature), int(top_k), float(top_p), float(min_p), float(top_no),
                               float(repetition_penalty), float(repetition_penalty_decay), float(length_penalty),
-                              int(self.stop_token), int(rep_pen_passes), int(seed), int(offset))
+                              int(self.stop_token), int(rep_pen_passes), int(seed), int(offset),
+                              float(temperature), float(min_temperature), float(dry_multiplier), float(dry_base),
+                              int(dry_allowed_length), 0)
 
     def sample(self, logits, prev_list=None, **sampling_kwargs):
         """``Base.sample`` (base.py:1280-1430): logits = list of per-utterance (rows, vocab) tensors; with
