@@ -326,8 +326,101 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
     }
 }
 
+// Greedy fast path: ONE WAVE per row, the row lives in registers (NJ values per lane), every reduction is a
+// wave reduction -- no LDS, no barriers, a few hundred instructions.  Covers what the AR decode loop and the
+// NAR levels run by default: argmax (temperature <= 0) with or without top-n-sigma and nothing else switched
+// on.  Same formulas as sample_kernel (token = lowest index of the row maximum; 0 when the row holds inf/nan
+// under top-n-sigma; score = softmax(processed)[token]), same fused AR bookkeeping and next-step prologue.
+template <int NJ>
+__global__ __launch_bounds__(64) void sample_greedy_wave_kernel(SampleArgs a) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const int V = a.vocab;
+    const int item = a.row_item ? a.row_item[row] : row;
+    const float* lg = a.logits + (size_t)row * a.ld;
+    float x[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const int v = lane + 64 * j; x[j] = v < V ? lg[v] : -INFINITY; }
+    int n_prev = 0;
+    if (a.prev_is_seq) n_prev = a.seq_len[item];
+    else if (a.prev != nullptr) n_prev = a.prev_len[item];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) mx = fmaxf(mx, x[j]);
+    mx = wave_max(mx);
+    bool all_masked = false;
+    if (a.p.top_no > 0.0f) {                                   // samplers.py:164-172, n = 1
+        float sum = 0.f;
+        int bad = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) if (lane + 64 * j < V) { if (!(fabsf(x[j]) <= 3.0e38f)) bad = 1; sum += x[j]; }
+        sum = wave_sum(sum);
+        all_masked = __any(bad);
+        const float mean = sum / (float)V;
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) if (lane + 64 * j < V) { const float dlt = x[j] - mean; ss += dlt * dlt; }
+        ss = wave_sum(ss);
+        const float thr = mx - sqrtf(ss / (float)(V - 1));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) if (all_masked || !(x[j] >= thr)) x[j] = -INFINITY;
+        if (all_masked) mx = -INFINITY;
+    }
+    float se = 0.f;
+    int best = 1 << 30;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int v = lane + 64 * j;
+        if (v < V) {
+            se += expf(x[j] - mx);                              // all -inf: exp(nan), like the reference's softmax
+            if (x[j] == mx && v < best) best = v;
+        }
+    }
+    se = wave_sum(se);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+    int tok = best;
+    if (tok >= V || all_masked) tok = 0;                        // torch.argmax of an all -inf / nan row
+    if (lane == 0) {
+        a.ids[row] = tok;
+        if (a.scores) a.scores[row] = 1.0f / se;               // exp(x[tok] - mx) = 1; nan when the row is all -inf / nan
+        if (a.seq != nullptr) {                                 // fused AR append (models/ar_nar.py:837-842)
+            const int n = a.seq_len[item];
+            if (n < a.seq_cap) a.seq[(size_t)item * a.seq_cap + n] = tok;
+            a.seq_len[item] = n + 1;
+            a.ctx_len[item] = a.ctx_len[item] + 1;
+            if (tok == a.p.stop_token) a.stopped[item] = 1;
+        }
+    }
+    if (a.nx_x != nullptr) {                                    // next step's fragment-order x, ssq and position
+        const bf16* src = a.nx_emb + (size_t)(a.nx_row0 + tok) * a.nx_d;
+        for (int c = lane * 8; c < a.nx_d; c += 64 * 8) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c);
+            float q2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q2 = fmaf((float)v[e], (float)v[e], q2);
+            q2 += __shfl_xor(q2, 1, 64);
+            *reinterpret_cast<bf16x8*>(a.nx_x + (size_t)(item >> 4) * 16 * a.nx_d + ((((c >> 5) << 6) + (((c >> 3) & 3) << 4) + (item & 15)) << 3)) = v;
+            if ((lane & 1) == 0) a.nx_ssq[(size_t)item * (a.nx_d >> 4) + (c >> 4)] = q2;
+        }
+        if (lane == 0) a.nx_pos[item] = (a.nx_pos0 ? a.nx_pos0[item] : 0) + n_prev;
+    }
+}
+
+static bool sample_is_plain_greedy(const SampleArgs& a) {
+    const valle_sample_params& p = a.p;
+    const bool has_prev = a.prev != nullptr || a.prev_is_seq;
+    return p.temperature <= 0.0f && p.temperature64 == p.min_temperature64 && p.top_k <= 0 && p.top_p >= 1.0f &&
+           p.min_p <= 0.0f && (p.repetition_penalty == 1.0f || !has_prev) && (p.length_penalty == 0.0f || a.nar_mode || !has_prev) &&
+           !(p.dry_multiplier > 0.0 && has_prev && p.dry_allowed_length < 2);
+}
+
 int valle_sample_launch(const SampleArgs& a, int rows, hipStream_t s) {
-    sample_kernel<<<rows, SAMP_THREADS, 0, s>>>(a);
+    if (sample_is_plain_greedy(a)) {
+        if (a.vocab <= 64 * 17) sample_greedy_wave_kernel<17><<<rows, 64, 0, s>>>(a);
+        else sample_greedy_wave_kernel<32><<<rows, 64, 0, s>>>(a);
+    } else {
+        sample_kernel<<<rows, SAMP_THREADS, 0, s>>>(a);
+    }
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
 }
