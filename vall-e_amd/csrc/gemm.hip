@@ -425,6 +425,14 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
 
 static int gemm_glds_dispatch(const void* A, const void* W, const void* bias, const void* resid, void* C,
                               int M, int N, int K, int ldc, int epi, hipStream_t s) {
+    // down_proj (K = d_ff >= 2048, narrow N): 64 K-tiles amortise the 256^2 ping-pong kernel's fill and epilogue even
+    // though N = 1024 gives only 4 x ceil(M/256) workgroups (measured 113.6 vs 133.5 us at M = 12,176)
+    if (epi == VALLE_EPI_RESID && K >= 2048 && M >= 2048 && N >= 256) {
+        dim3 g256(ceil_div(N, 256), ceil_div(M, 256));
+        gemm_pp256_bf16_kernel<VALLE_EPI_RESID><<<g256, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
+        VALLE_LAUNCH_CHECK();
+        return VALLE_OK;
+    }
     if (N <= 1024 && epi == VALLE_EPI_RESID) {      // narrow outputs: smaller tile, whole rounds of workgroups
         dim3 g64(ceil_div(N, 64), ceil_div(M, 128));
         gemm_glds_n64_bf16_kernel<VALLE_EPI_RESID><<<g64, 256, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
