@@ -195,3 +195,37 @@ def test_len_task_plan_and_inputs():
     plain = host_model()
     with pytest.raises(Exception, match="len"):
         plain.plan(phns, langs, proms, [None] * 3, 0, task="len", len_list=seqs)
+
+
+def test_phoneme_tokenizer_known_answers():
+    """utils/tokenizer.py (BPE restatement) against the ids of the library the reference tokenizes with, on the
+    reference's own tokenizer.json; includes the phoneme string bundled with data/qnt.enc (BASELINE configs[0])."""
+    import json
+    from vall_e_amd.utils.tokenizer import PhonemeTokenizer
+    from vall_e_amd.synth import QNT_ENC_PHONEME_IDS
+    tok = PhonemeTokenizer.from_file(ROOT / "tests" / "golden" / "tokenizer.json")
+    kat = json.loads((ROOT / "tests" / "golden" / "tokenizer_kat.json").read_text(encoding="utf-8"))
+    assert len(kat["cases"]) == 200
+    for text, ids in kat["cases"]:
+        assert tok.encode(text) == ids, text
+    assert tok.encode("wˈʌns ɐɡˈɛn, ˈɛksələnt wˈɜːk.") == QNT_ENC_PHONEME_IDS
+    assert tok.encode(list("ðə kˈæt")) == tok.encode("ðə kˈæt")                  # data.py:640-642 joins phoneme lists
+    assert tok.encode("ab", add_special_tokens=False) == tok.encode("ab")[1:-1]
+    assert tok.decode(tok.encode("ðə kˈæt"), skip_special_tokens=True) == "ðə kˈæt"
+    assert tok.get_vocab()["<bos>"] == 1
+
+
+def test_tts_text_front_end_ids():
+    """TTS.encode_text / encode_lang (inference.py:111-137) on phoneme strings; tensors pass through."""
+    from vall_e_amd.inference import TTS
+    from vall_e_amd.synth import QNT_ENC_PHONEME_IDS
+    tts = TTS.__new__(TTS)
+    tts.tokenizer = None
+    with pytest.raises(RuntimeError, match="tokenizer"):
+        tts.encode_text("ðə")
+    tts.load_tokenizer(ROOT / "tests" / "golden" / "tokenizer.json")
+    ids = tts.encode_text("wˈʌns ɐɡˈɛn, ˈɛksələnt wˈɜːk.")
+    assert ids.dtype == torch.int16 and ids.tolist() == QNT_ENC_PHONEME_IDS
+    t = torch.tensor([1, 5, 2])
+    assert tts.encode_text(t) is t
+    assert tts.encode_lang("de").tolist() == [2] and tts.encode_lang("xx").tolist() == [0]

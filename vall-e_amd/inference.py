@@ -114,10 +114,35 @@ class TTS:
         self.dtype = dtype if dtype is not None else torch.float32        # data/config.yaml:118 weight_dtype float32
         self.amp = bool(amp)
         self.batch_size = 16                                               # config.py:856
+        self.tokenizer = None
         if state_dict is None:
             from .weights import synth_state_dict
             state_dict = synth_state_dict(self.config, seed)
         self.model = get_model(self.config).load_state_dict(state_dict).to(self.device, self.dtype)
+
+    # ---------------------------------------------------------------- text front end (ids only)
+    LANG_SYMMAP = {"en": 0, "ja": 1, "de": 2, "fr": 3, "zh": 4, "ko": 5}     # data.py:650-658
+
+    def load_tokenizer(self, path):
+        """The reference's phoneme tokenizer file (data/tokenizer.json, config.py:1170-1184)."""
+        from .utils.tokenizer import PhonemeTokenizer
+        self.tokenizer = PhonemeTokenizer.from_file(path)
+        return self.tokenizer
+
+    def encode_text(self, text, language="auto", precheck=True, phonemize=True):
+        """inference.py:111-129 for input that is already phonemes: a tensor passes through, an IPA string is
+        tokenised (``<bos> ... <eos>``).  Grapheme-to-phoneme conversion (espeak through ``phonemizer``,
+        emb/g2p.py) is not part of this package, so plain text must be phonemized by the caller."""
+        if isinstance(text, torch.Tensor):
+            return text
+        if getattr(self, "tokenizer", None) is None:
+            raise RuntimeError("no tokenizer loaded: call load_tokenizer(path to the reference's data/tokenizer.json)")
+        ids = self.tokenizer.encode(text)
+        return torch.tensor(ids, dtype=torch.uint8 if len(self.tokenizer.get_vocab()) < 256 else torch.int16)   # inference.py:284
+
+    def encode_lang(self, language):
+        """inference.py:131-137."""
+        return torch.tensor([self.LANG_SYMMAP.get(language, 0)], dtype=torch.uint8)
 
     def modality(self, modality):
         """inference.py:210-214: 'auto' resolves to the model's name when that names a modality."""
@@ -137,6 +162,9 @@ class TTS:
             sampling_kwargs.pop(k, None)
         duration_padding = sampling_kwargs.pop("duration_padding", 1.05)
         n = len(texts)
+        texts = [self.encode_text(t) for t in texts]                          # IPA strings -> ids (inference.py:284)
+        if languages and isinstance(languages[0], str):
+            languages = [self.encode_lang(l) for l in languages]              # inference.py:286
         references = list(references) if references else [None] * n
         languages = list(languages) if languages else [torch.tensor([0], dtype=torch.uint8)] * n
         lengths = [sort_key(t, r) for t, r in zip(texts, references)]
