@@ -78,7 +78,7 @@ int main(int argc, char** argv) {
     auto mkw = [&](const bf16* xx, int norm, const bf16* W, const bf16* resid, void* out, int ldo, int N, int K) {
         DecWArgs a{}; a.x = xx; a.norm = norm; a.eps = 1e-6f; a.W = W; a.resid = resid; a.out = out; a.ldo = ldo; a.B = B; a.N = N; a.K = K; a.ssq_in = ssq; a.ssq_out = resid ? ssq : nullptr; return a; };
     auto w_qkv = [&](int l) { DecWArgs a = mkw(x, 1, wqkv[l], nullptr, qkv, 3 * d, 3 * d, d);
-        a.rope = rope; a.pos = pos; a.ctx_len = ctxl; a.slot = nullptr; a.kc = kc[l]; a.vc = vc[l]; a.cache_T = CT; a.H = H; a.d = d;
+        a.rope_m = rope; a.ctx_len = ctxl; a.slot = nullptr; a.kc = kc[l]; a.vc = vc[l]; a.cache_T = CT; a.H = H; a.d = d;
         return valle_dec_wave_linear(a, DEC_EPI_QKV, s); };
     auto w_o = [&](int l) { return valle_dec_wave_linear(mkw(att, 0, wo[l], x, x, d, d, d), VALLE_EPI_RESID, s); };
     auto w_gu = [&](int l) { return valle_dec_wave_linear(mkw(x, 1, wgu[l], nullptr, ff, f, 2 * f, d), VALLE_EPI_GEGLU, s); };

@@ -93,6 +93,7 @@ struct SampleArgs {
     // optional fused prologue of the NEXT decode step (wave-streaming path): embed the sampled token into the
     // fragment-order x, its per-tile sums of squares and its RoPE position
     const bf16* nx_emb; int nx_row0; bf16* nx_x; float* nx_ssq; int32_t* nx_pos; const int32_t* nx_pos0; int nx_d;
+    const float* nx_rope_tab; float* nx_rope;   // RoPE table [P][64] -> the new position's row, [32][64]
 };
 int valle_sample_launch(const SampleArgs& a, int rows, hipStream_t s);
 
@@ -105,7 +106,8 @@ struct DecWArgs {
     float eps; int norm;
     const float* ssq_in;        // norm: [16][K/16] per-tile sums of squares of x's rows
     float* ssq_out;             // RESID: [16][N/16] the same for the rows this kernel writes (may be NULL)
-    const float* rope; const int32_t* pos; const int32_t* ctx_len; const int32_t* slot;
+    const float* rope_m;        // QKV: [32][64] (cos, sin) row of every utterance's position
+    const int32_t* ctx_len; const int32_t* slot;
     bf16* kc; bf16* vc; int cache_T; int H; int d;
 };
 int valle_dec_wave_linear(const DecWArgs& a, int epilogue, hipStream_t s);

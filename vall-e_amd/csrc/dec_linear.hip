@@ -52,10 +52,9 @@ __global__ __launch_bounds__(64 * NWK) void dec_wave_kernel(DecWArgs a) {
         if constexpr (EPI == VALLE_EPI_RESID) {
             if (wave == 0) rs = *reinterpret_cast<const bf16x4*>(a.resid + (size_t)mt * 16 * a.N + frag_off(fr, n));
         } else if constexpr (EPI == DEC_EPI_QKV) {
-            const int p = a.pos[mc];
             cpos = a.ctx_len[mc];
             csl = a.slot ? a.slot[mc] : mc;
-            rp = *reinterpret_cast<const f32x4*>(a.rope + (size_t)p * 64 + (n & 63));   // (cos,sin) of pairs n/2, n/2+1
+            rp = *reinterpret_cast<const f32x4*>(a.rope_m + (size_t)mc * 64 + (n & 63));   // (cos,sin) of pairs n/2, n/2+1
         }
         // ---- 2. per-row sum of squares: partial sums per 16-column tile, left by the producer of x
         // (ssq[m][K/16]); this lane adds tiles fq*STEPS .. +STEPS of its row

@@ -84,11 +84,14 @@ __global__ __launch_bounds__(128) void dec_prepare_frag_kernel(const bf16* __res
                                                                const int32_t* __restrict__ seq_len,
                                                                const int32_t* __restrict__ resp_pos0,
                                                                bf16* __restrict__ xf, float* __restrict__ ssq,
-                                                               int32_t* __restrict__ pos, int d) {
+                                                               int32_t* __restrict__ pos, int d,
+                                                               const float* __restrict__ rope_tab, float* __restrict__ rope_m) {
     const int b = blockIdx.x;
     const int n = seq_len[b];
     const int tok = seq[(size_t)b * seq_cap + (n - 1)];
-    if (threadIdx.x == 0) pos[b] = (resp_pos0 ? resp_pos0[b] : 0) + n - 1;
+    const int p = (resp_pos0 ? resp_pos0[b] : 0) + n - 1;
+    if (threadIdx.x == 0) pos[b] = p;
+    if (threadIdx.x < 64) rope_m[b * 64 + threadIdx.x] = rope_tab[(size_t)p * 64 + threadIdx.x];   // this position's (cos, sin) row
     const bf16* src = emb + (size_t)(emb_row0 + tok) * d;
     for (int c = threadIdx.x * 8; c < d; c += 128 * 8) {
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c);
@@ -184,6 +187,7 @@ extern "C" size_t valle_decode_workspace_bytes(const valle_model* m, int B) {
     t += align_up((size_t)(B + 1) * sizeof(int32_t), 256) * 2 + align_up((size_t)B * sizeof(int32_t), 256);
     t += align_up((size_t)32 * (d / 16) * sizeof(float), 256);   // per-tile sums of squares (wave-streaming path)
     t += align_up((size_t)32 * d * es, 256) * 2 + align_up((size_t)32 * f * es, 256);  // its fragment-order x, att, ff (16-row tiles)
+    t += align_up((size_t)32 * 64 * sizeof(float), 256);                // RoPE rows of the current positions
     return t;
 }
 
@@ -214,6 +218,7 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
     bf16* xf = (bf16*)ws.take((size_t)32 * d * es);
     bf16* attf = (bf16*)ws.take((size_t)32 * d * es);
     bf16* fff = (bf16*)ws.take((size_t)32 * f * es);
+    float* rope_m = (float*)ws.take((size_t)32 * 64 * sizeof(float));   // (cos, sin) row of every utterance's current position
     VALLE_REQUIRE(ws.ok, VALLE_E_WORKSPACE, "valle_ar_decode: workspace %zu B too small (need %zu)", workspace_bytes,
                   valle_decode_workspace_bytes(m, B));
     hipStream_t s = (hipStream_t)stream;
@@ -226,7 +231,7 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
         if (wavepath && step > 0) {
             // the previous step's sampler already embedded its token (SampleArgs.nx_*)
         } else if (wavepath)
-            dec_prepare_frag_kernel<<<B, 128, 0, s>>>((const bf16*)m->emb, st->resp_emb_row0, st->seq, st->max_steps, st->seq_len, st->resp_pos0, xf, ssq, pos, d);
+            dec_prepare_frag_kernel<<<B, 128, 0, s>>>((const bf16*)m->emb, st->resp_emb_row0, st->seq, st->max_steps, st->seq_len, st->resp_pos0, xf, ssq, pos, d, m->rope, rope_m);
         else if (dt == VALLE_BF16)
             dec_prepare_kernel<bf16><<<B, 128, 0, s>>>((const bf16*)m->emb, st->resp_emb_row0, st->seq, st->max_steps, st->seq_len, st->resp_pos0, (bf16*)x, pos, cu, d, B);
         else
@@ -240,7 +245,7 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
                 DecWArgs a{};
                 a.x = xf; a.W = (const bf16*)w.pn_qkv; a.out = qkv; a.ldo = 3 * d; a.B = B; a.N = 3 * d; a.K = d;
                 a.eps = c.rms_eps; a.norm = 1; a.ssq_in = ssq;
-                a.rope = m->rope; a.pos = pos; a.ctx_len = st->ctx_len; a.slot = st->cache_slot;
+                a.rope_m = rope_m; a.ctx_len = st->ctx_len; a.slot = st->cache_slot;
                 a.kc = (bf16*)kc; a.vc = (bf16*)vc; a.cache_T = st->cache_T; a.H = H; a.d = d;
                 RUN(valle_dec_wave_linear(a, DEC_EPI_QKV, s));
                 RUN(valle_attn_decode_bf16(qkv, (size_t)3 * d, kc, vc, st->ctx_len, st->cache_slot, attf, B, H, st->cache_T, 1, 1, s));
@@ -280,7 +285,7 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
         sa.ids = wavepath ? cu : pos;  // scratch: the token also lands in seq
         if (wavepath && step + 1 < n_steps) {
             sa.nx_emb = (const bf16*)m->emb; sa.nx_row0 = st->resp_emb_row0; sa.nx_x = xf; sa.nx_ssq = ssq;
-            sa.nx_pos = pos; sa.nx_pos0 = st->resp_pos0; sa.nx_d = d;
+            sa.nx_pos = pos; sa.nx_pos0 = st->resp_pos0; sa.nx_d = d; sa.nx_rope_tab = m->rope; sa.nx_rope = rope_m;
         }
         sa.scores = st->scores;
         sa.seq = st->seq; sa.seq_cap = st->max_steps; sa.seq_len = st->seq_len; sa.ctx_len = st->ctx_len; sa.stopped = st->stopped;

@@ -322,7 +322,9 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
             *reinterpret_cast<bf16x8*>(a.nx_x + (size_t)(item >> 4) * 16 * a.nx_d + ((((c >> 5) << 6) + (((c >> 3) & 3) << 4) + (item & 15)) << 3)) = v;
             if ((tid & 1) == 0) a.nx_ssq[(size_t)item * (a.nx_d >> 4) + (c >> 4)] = q2;
         }
-        if (tid == 0) a.nx_pos[item] = (a.nx_pos0 ? a.nx_pos0[item] : 0) + n_prev;   // position of token index n_prev
+        const int npos = (a.nx_pos0 ? a.nx_pos0[item] : 0) + n_prev;                  // position of token index n_prev
+        if (tid == 0) a.nx_pos[item] = npos;
+        if (tid < 64 && a.nx_rope) a.nx_rope[item * 64 + tid] = a.nx_rope_tab[(size_t)npos * 64 + tid];
     }
 }
 
@@ -402,7 +404,9 @@ __global__ __launch_bounds__(64) void sample_greedy_wave_kernel(SampleArgs a) {
             *reinterpret_cast<bf16x8*>(a.nx_x + (size_t)(item >> 4) * 16 * a.nx_d + ((((c >> 5) << 6) + (((c >> 3) & 3) << 4) + (item & 15)) << 3)) = v;
             if ((lane & 1) == 0) a.nx_ssq[(size_t)item * (a.nx_d >> 4) + (c >> 4)] = q2;
         }
-        if (lane == 0) a.nx_pos[item] = (a.nx_pos0 ? a.nx_pos0[item] : 0) + n_prev;
+        const int npos = (a.nx_pos0 ? a.nx_pos0[item] : 0) + n_prev;
+        if (lane == 0) a.nx_pos[item] = npos;
+        if (a.nx_rope) a.nx_rope[item * 64 + lane] = a.nx_rope_tab[(size_t)npos * 64 + lane];
     }
 }
 
