@@ -43,33 +43,10 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, 
     return ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);
 }
 
-// descending bitonic sort of (key,val) pairs in LDS; n2 = power of two
-__device__ void bitonic_desc(float* key, int* val, int n2) {
-    for (int k = 2; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            __syncthreads();
-            for (int i = threadIdx.x; i < n2; i += SAMP_THREADS) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const bool desc = (i & k) == 0;
-                    const float a = key[i], b = key[ixj];
-                    // order: larger first; NaN never produced here; ties keep lower index first
-                    const bool swap = desc ? (a < b || (a == b && val[i] > val[ixj])) : (a > b || (a == b && val[i] < val[ixj]));
-                    if (swap) {
-                        key[i] = b; key[ixj] = a;
-                        const int t = val[i]; val[i] = val[ixj]; val[ixj] = t;
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-}
-
 __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
-    __shared__ float vals[SAMP_MAXV];
-    __shared__ float skey[SAMP_MAXV];
-    __shared__ int sidx[SAMP_MAXV];
+    __shared__ __attribute__((aligned(16))) float vals[SAMP_MAXV];
+    __shared__ __attribute__((aligned(16))) float skey[SAMP_MAXV];
+    __shared__ __attribute__((aligned(16))) int sidx[SAMP_MAXV];
     __shared__ float red[SAMP_THREADS / 64];
     __shared__ double red64[SAMP_THREADS / 64];
     __shared__ int s_flag;
@@ -93,27 +70,56 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
         prev = a.prev + a.prev_off[item];
     }
 
-    // ---- repetition penalty (samplers.py:16-50)
+    // Ordered application of one operand per previous token (repetition penalty: divide, DRY: subtract).  The tokens
+    // and their operands (computed in parallel by all threads) are staged through LDS in tiles; wave 0 then takes 64
+    // positions at a time, one per lane.  Positions with different tokens commute and are applied together; positions
+    // of the SAME token must keep their sequence order (x / d1 / d2 is not x / d2 / d1 in floating point), so every
+    // pending lane bids for its token with its lane number (LDS min), the lowest -- earliest -- bidder applies its
+    // operand and clears the bid, and the others try again.  A 2,000-token history costs ~10 us.
+    constexpr int NK = SAMP_MAXV / SAMP_THREADS;
+    const int nkv = (V + SAMP_THREADS - 1) / SAMP_THREADS;
+    __shared__ int claim[SAMP_MAXV];
+    for (int v = tid; v < SAMP_MAXV; v += SAMP_THREADS) claim[v] = 0x7fffffff;
+    auto ordered_apply = [&](int limit, bool subtract, auto operand) {
+        for (int t0 = 0; t0 < limit; t0 += SAMP_MAXV) {
+            const int nt = min(limit - t0, SAMP_MAXV);
+            __syncthreads();
+            for (int i = tid; i < nt; i += SAMP_THREADS) {
+                sidx[i] = prev[t0 + i];
+                skey[i] = operand(t0 + i);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                for (int base = 0; base < nt; base += 64) {
+                    const int i = base + tid;
+                    const int tok = i < nt ? sidx[i] : -1;
+                    const float dv = i < nt ? skey[i] : 1.f;
+                    bool pending = (unsigned)tok < (unsigned)V;
+                    while (__ballot(pending)) {
+                        if (pending) atomicMin(&claim[tok], tid);
+                        if (pending && claim[tok] == tid) {
+                            const float cur = vals[tok];
+                            vals[tok] = subtract ? cur - dv : cur / dv;
+                            claim[tok] = 0x7fffffff;
+                            pending = false;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    };
+
+    // ---- repetition penalty (samplers.py:16-50): for every previous token, in order, logit[token] /= factor * distance^decay
     if (a.p.repetition_penalty != 1.0f && prev != nullptr && n_prev > 0) {
         int limit;
         if (a.nar_mode) limit = a.row_in_item ? a.row_in_item[row] : 0;  // only tokens before this row
         else limit = (n_prev == 1) ? 0 : n_prev;                           // 1 row & 1 prev => "NAR": start=1 empties the slice
         if (limit > n_prev) limit = n_prev;
         const double factor = (double)a.p.repetition_penalty, decay = (double)a.p.repetition_penalty_decay;
-        for (int pass = 0; pass < a.p.rep_pen_passes; ++pass) {
-            for (int v = tid; v < V; v += SAMP_THREADS) {
-                float x = vals[v];
-                for (int i = 0; i < limit; ++i) {
-                    if (prev[i] == v) {
-                        const double dist = (double)(n_prev - i);
-                        const float div = (float)(decay == 0.0 ? factor : factor * pow(dist, decay));
-                        x = x / div;
-                    }
-                }
-                vals[v] = x;
-            }
-        }
-        __syncthreads();
+        const float fdiv = (float)factor;
+        for (int pass = 0; pass < a.p.rep_pen_passes; ++pass)
+            ordered_apply(limit, false, [&](int i) { return decay == 0.0 ? fdiv : (float)(factor * pow((double)(n_prev - i), decay)); });
     }
     // ---- length penalty, AR rows only (samplers.py:56-61; length = len(prev) + 1, base.py:1377)
     if (!a.nar_mode && a.p.length_penalty != 0.0f && (prev != nullptr || a.prev_is_seq) && a.p.stop_token < V) {
@@ -124,75 +130,115 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
         __syncthreads();
     }
 
-    const bool need_sort = a.p.top_k > 0 || a.p.top_p < 1.0f || a.p.min_p > 0.0f;
-    int n2 = 1;
-    while (n2 < V) n2 <<= 1;
-    auto sort_current = [&]() {
-        for (int i = tid; i < n2; i += SAMP_THREADS) {
-            skey[i] = i < V ? vals[i] : -INFINITY;
-            sidx[i] = i < V ? i : (1 << 30);
+    // Order statistics without sorting.  Every column gets a 64-bit key that orders like a stable descending sort of the
+    // logits does -- (monotone image of the float) << 32 | ~index, so a larger logit, then a lower index, is a larger key
+    // and no two keys are equal.  "The k-th largest key" and "the lowest-ranked column whose preceding softmax mass is
+    // still <= P" are then found by a bit-by-bit binary search over the key, each probe one block reduction over the
+    // 4-5 columns a thread holds in registers: 43 probes (32 value bits + 11 index bits) instead of a 66-phase bitonic sort.
+    typedef unsigned long long u64;
+    u64 key[NK];
+    float ev[NK];
+    auto load_keys = [&](float mx) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int v = tid + SAMP_THREADS * k;
+            if (v < V) {
+                const float x = vals[v];
+                unsigned u = __float_as_uint(x);
+                u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                key[k] = ((u64)u << 32) | (unsigned)(~v);
+                ev[k] = expf(x - mx);
+            } else { key[k] = 0; ev[k] = 0.f; }
         }
-        bitonic_desc(skey, sidx, n2);
+    };
+    __shared__ int cnt_red[SAMP_THREADS / 64];
+    auto block_count = [&](int c) {
+        c = (int)wave_sum((float)c);                 // <= 2048: exact in fp32
+        __syncthreads();
+        if ((tid & 63) == 0) cnt_red[tid >> 6] = c;
+        __syncthreads();
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < SAMP_THREADS / 64; ++i) t += cnt_red[i];
+        return t;
+    };
+    // largest T with #(key >= T) >= k, i.e. the k-th largest key (1 <= k <= V)
+    auto kth_largest_key = [&](int k) {
+        u64 T = 0xFFFFF800ull;                       // bits 31..11 are ones in every key (index < 2048)
+        for (int bit = 63; bit >= 0; --bit) {
+            if (bit < 32 && bit > 10) continue;
+            const u64 cand = T | (1ull << bit);
+            int c = 0;
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) c += (kk < nkv && key[kk] >= cand) ? 1 : 0;
+            if (block_count(c) >= k) T = cand;
+        }
+        return T;
     };
     // ---- min-p (samplers.py:74-90): drop p < min_p * p_max, but never the 32 largest
     if (a.p.min_p > 0.0f) {
-        sort_current();
-        const float mx = skey[0];
+        float mx = -INFINITY;
+        for (int v = tid; v < V; v += SAMP_THREADS) mx = fmaxf(mx, vals[v]);
+        mx = block_reduce_max(mx, red);
+        load_keys(mx);
         float se = 0.f;
-        for (int v = tid; v < V; v += SAMP_THREADS) se += expf(vals[v] - mx);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) se += ev[k];
         se = block_reduce_sum(se, red);
         const float thr = a.p.min_p * (1.0f / se);  // p_max = exp(0)/se
+        const u64 k32 = V > 32 ? kth_largest_key(32) : 0;
         __syncthreads();
-        for (int j = tid; j < V; j += SAMP_THREADS) {
-            if (j >= 32) {
-                const int v = sidx[j];
-                if (expf(skey[j] - mx) / se < thr) vals[v] = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int v = tid + SAMP_THREADS * k;
+            if (v < V && key[k] < k32 && ev[k] / se < thr) vals[v] = -INFINITY;
+        }
+        __syncthreads();
+    }
+    // ---- top-k (samplers.py:102-106): keep logits >= the k-th largest value (ties kept); top-p (:108-123): softmax of
+    // what is left, drop a column when the mass ranked before it exceeds top_p (the first column always stays)
+    if (a.p.top_k > 0 || a.p.top_p < 1.0f) {
+        float mx = -INFINITY;
+        for (int v = tid; v < V; v += SAMP_THREADS) mx = fmaxf(mx, vals[v]);
+        mx = block_reduce_max(mx, red);
+        load_keys(mx);
+        u64 kth_hi = 0;                              // value part of the k-th largest key; columns with a smaller value go
+        if (a.p.top_k > 0) {
+            int k = a.p.top_k < 1 ? 1 : a.p.top_k;
+            if (k > V) k = V;
+            kth_hi = kth_largest_key(k) >> 32;
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk)
+                if ((key[kk] >> 32) < kth_hi) ev[kk] = 0.f;      // exp(-inf - max) = 0 in the softmax that follows
+        }
+        u64 cut = 0;                                 // columns with key < cut are dropped by top-p
+        if (a.p.top_p < 1.0f) {
+            float se = 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) se += ev[k];
+            se = block_reduce_sum(se, red);
+            const float budget = a.p.top_p * se;     // mass ranked before a column must not exceed this
+            // smallest T with sum(e_u : key_u > T) <= budget
+            u64 T = ~0ull;
+            for (int bit = 63; bit >= 0; --bit) {
+                if (bit < 32 && bit > 10) continue;
+                const u64 cand = T & ~(1ull << bit);
+                float g = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < NK; ++kk) g += (key[kk] > cand) ? ev[kk] : 0.f;
+                g = block_reduce_sum(g, red);
+                if (g <= budget) T = cand;
             }
+            cut = T;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            const int v = tid + SAMP_THREADS * kk;
+            if (v < V && ((key[kk] >> 32) < kth_hi || key[kk] < cut)) vals[v] = -INFINITY;
         }
         __syncthreads();
     }
-    // ---- top-k (samplers.py:102-106): keep logits >= the k-th largest
-    if (a.p.top_k > 0) {
-        sort_current();
-        int k = a.p.top_k < 1 ? 1 : a.p.top_k;
-        if (k > V) k = V;
-        const float kth = skey[k - 1];
-        __syncthreads();
-        for (int v = tid; v < V; v += SAMP_THREADS) if (vals[v] < kth) vals[v] = -INFINITY;
-        __syncthreads();
-    }
-    // ---- top-p (samplers.py:108-123)
-    if (a.p.top_p < 1.0f) {
-        sort_current();
-        const float mx = skey[0];
-        // softmax of the sorted logits, inclusive cumsum (Hillis-Steele over n2 in LDS, reusing vals? no: use skey)
-        float se = 0.f;
-        for (int j = tid; j < V; j += SAMP_THREADS) se += expf(skey[j] - mx);
-        se = block_reduce_sum(se, red);
-        __syncthreads();
-        for (int j = tid; j < n2; j += SAMP_THREADS) skey[j] = j < V ? expf(skey[j] - mx) / se : 0.f;
-        __syncthreads();
-        // serial-chunk scan: each thread owns a contiguous chunk
-        const int chunk = n2 / SAMP_THREADS > 0 ? n2 / SAMP_THREADS : 1;
-        const int b0 = tid * chunk;
-        float run = 0.f;
-        if (b0 < n2) for (int j = b0; j < b0 + chunk; ++j) { run += skey[j]; skey[j] = run; }
-        __shared__ float chunk_tot[SAMP_THREADS];
-        chunk_tot[tid] = (b0 < n2) ? run : 0.f;
-        __syncthreads();
-        if (tid == 0) {
-            float acc = 0.f;
-            for (int t = 0; t < SAMP_THREADS; ++t) { const float c = chunk_tot[t]; chunk_tot[t] = acc; acc += c; }
-        }
-        __syncthreads();
-        if (b0 < n2) for (int j = b0; j < b0 + chunk; ++j) skey[j] += chunk_tot[tid];
-        __syncthreads();
-        // remove sorted position j >= 1 when cum[j-1] > top_p
-        for (int j = tid + 1; j < V; j += SAMP_THREADS)
-            if (skey[j - 1] > a.p.top_p) vals[sidx[j]] = -INFINITY;
-        __syncthreads();
-    }
-    (void)need_sort;
     // ---- dynamic temperature (samplers.py:128-141) or plain temperature (base.py:1389-1392)
     if (a.p.temperature64 != a.p.min_temperature64) {
         float mxr = -INFINITY;
@@ -243,26 +289,20 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
         __syncthreads();
     }
     // ---- DRY (samplers.py:248-275 as it runs: one entry per POSITION of prev, in order; the loop stops at the
-    // first entry shorter than allowed_length, and position 0 always has length 1)
+    // first entry shorter than allowed_length, and position 0 always has length 1, so allowed_length >= 2 is a no-op)
     if (a.p.dry_multiplier > 0.0 && prev != nullptr && n_prev > 0 && a.p.dry_allowed_length < 2) {
         const int allowed = a.p.dry_allowed_length;
         const int cap = allowed > 50 ? allowed : 50;
-        for (int v = tid; v < V; v += SAMP_THREADS) {
-            float x = vals[v];
-            for (int i = 0; i < n_prev; ++i) {
-                if (prev[i] != v) continue;
-                int length = 1;
-                while (length < cap) {
-                    const int j = i - length;
-                    if (j < 0) break;
-                    if (prev[j] != prev[n_prev - length - 1]) break;
-                    ++length;
-                }
-                x = x - (float)(a.p.dry_multiplier * pow(a.p.dry_base, (double)(length - allowed)));
+        ordered_apply(n_prev, true, [&](int i) {
+            int length = 1;
+            while (length < cap) {
+                const int j = i - length;
+                if (j < 0) break;
+                if (prev[j] != prev[n_prev - length - 1]) break;
+                ++length;
             }
-            vals[v] = x;
-        }
-        __syncthreads();
+            return (float)(a.p.dry_multiplier * pow(a.p.dry_base, (double)(length - allowed)));
+        });
     }
     // ---- pick: argmax (lowest index on ties) or categorical
     float mx = -INFINITY;
@@ -282,18 +322,40 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
         tok = s_flag;
         if (tok >= V) tok = 0;          // all -inf / nan row: torch.argmax returns 0
     } else {
-        // inverse-CDF draw over the index order
-        if (tid == 0) {
-            const float u = philox_uniform(a.p.seed, a.p.offset + a.step, (uint32_t)row) * se;
-            float acc = 0.f;
-            int pick = -1, last_valid = 0;
-            for (int v = 0; v < V; ++v) {
-                const float e = expf(vals[v] - mx);
-                if (e > 0.f) last_valid = v;
-                acc += e;
-                if (pick < 0 && acc >= u) pick = v;
-            }
-            s_flag = pick < 0 ? last_valid : pick;
+        // inverse-CDF draw over the index order: e[v] = exp(logit - max), first v with cumsum(e)[v] >= u * sum(e);
+        // chunked scan (each thread owns a contiguous run of columns)
+        const float u = philox_uniform(a.p.seed, a.p.offset + a.step, (uint32_t)row) * se;
+        const int chunk = (V + SAMP_THREADS - 1) / SAMP_THREADS;
+        const int b0 = tid * chunk, b1 = min(b0 + chunk, V);
+        float run = 0.f;
+        int last_valid_loc = -1;
+        for (int v = b0; v < b1; ++v) {
+            const float e = expf(vals[v] - mx);
+            if (e > 0.f) last_valid_loc = v;
+            run += e;
+            skey[v] = run;                                   // running sum inside the chunk
+        }
+        __shared__ float draw_tot[SAMP_THREADS];
+        draw_tot[tid] = run;
+        if (tid == 0) s_flag = 1 << 30;
+        __syncthreads();
+        float before = 0.f;
+        for (int t = 0; t < tid; ++t) before += draw_tot[t];  // chunk offsets, summed in index order
+        int pick = 1 << 30;
+        for (int v = b0; v < b1; ++v)
+            if (before + skey[v] >= u) { pick = v; break; }
+        atomicMin(&s_flag, pick);
+        // fallback when rounding leaves the total below u: the last column with non-zero mass
+        int lv = last_valid_loc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) lv = max(lv, __shfl_xor(lv, o, 64));
+        __shared__ int draw_lv[SAMP_THREADS / 64];
+        if ((tid & 63) == 0) draw_lv[tid >> 6] = lv;
+        __syncthreads();
+        if (tid == 0 && s_flag >= V) {
+            int m = 0;
+            for (int w = 0; w < SAMP_THREADS / 64; ++w) m = max(m, draw_lv[w]);
+            s_flag = m;
         }
         __syncthreads();
         tok = s_flag;
