@@ -81,6 +81,13 @@ int valle_rmsnorm(const void* x, const void* w, void* out, int rows, int d, floa
 int valle_gemm(const void* A, const void* W, const void* bias, const void* resid, void* C,
                int M, int N, int K, int ldc, int epilogue, int dtype, void* stream);
 
+/* q/k/v projection with RoPE in the epilogue, for passes without a KV cache (bf16, head_dim 64,
+ * M >= 64, d % 64 == 0, K % 64 == 0): qkv[M][3d] = A[M][K] . w_qkv[3d][K]^T, the q and k parts
+ * rotated by rope[pos[m]] -- bit-identical to valle_gemm(EPI_STORE) followed by valle_rope_kv
+ * (arch/llama.py:307-309 + :48-61). */
+int valle_gemm_qkv_rope(const void* A, const void* w_qkv, const float* rope, const int32_t* pos, void* qkv,
+                        int M, int d, int K, void* stream);
+
 /* RoPE on the q and k parts of packed qkv rows [M][3d] (in place, pair-interleaved head
  * layout, see w_qkv) using the fp32 table rope[pos][Dh/2][2] = (cos, sin)
  * (arch/llama.py:82-132, :48-61), then optionally copies the rotated k and v rows into a

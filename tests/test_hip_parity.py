@@ -99,6 +99,29 @@ def test_gemm_epilogues(gpu_device, dtype, epi, shape):
     assert (got - want).abs().max().item() < (1e-4 if dtype == torch.float32 else 0.15)
 
 
+def test_gemm_qkv_rope_equals_gemm_then_rope(gpu_device):
+    """valle_gemm_qkv_rope (RoPE in the projection's epilogue) is bit-identical to valle_gemm + valle_rope_kv."""
+    from vall_e_amd import _lib as L
+    lib = L.load()
+    M, d, H = 333, 256, 4
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(M, d, generator=g).bfloat16().to(gpu_device)
+    W = (torch.randn(3 * d, d, generator=g) / d ** 0.5).bfloat16().to(gpu_device)
+    pos = torch.randint(0, 500, (M,), generator=g, dtype=torch.int32).to(gpu_device)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 64, 2).float() / 64))
+    fr = torch.arange(512).float()[:, None] * inv[None, :]
+    rope = torch.stack((fr.cos(), fr.sin()), dim=-1).contiguous().to(gpu_device)          # (P, 32, 2)
+    cu = torch.tensor([0, M], dtype=torch.int32, device=gpu_device)
+    a = torch.zeros((M, 3 * d), dtype=torch.bfloat16, device=gpu_device)
+    b = torch.zeros_like(a)
+    L.check(lib.valle_gemm(L.ptr(A), L.ptr(W), None, None, L.ptr(a), M, 3 * d, d, 3 * d, 0, L.dtype_code(torch.bfloat16), L.stream_ptr()))
+    L.check(lib.valle_rope_kv(L.ptr(a), L.ptr(pos), L.ptr(rope), L.ptr(cu), 1, M, H, 64, None, None, 0, None, None,
+                              L.dtype_code(torch.bfloat16), L.stream_ptr()))
+    L.check(lib.valle_gemm_qkv_rope(L.ptr(A), L.ptr(W), L.ptr(rope), L.ptr(pos), L.ptr(b), M, d, d, L.stream_ptr()))
+    assert torch.equal(a.cpu().view(torch.int16), b.cpu().view(torch.int16))
+    assert not torch.equal(a[:, :d].cpu(), (A.float() @ W[:d].float().T).bfloat16().cpu())       # the rotation did something
+
+
 def test_sampler_known_answers(gpu_device):
     """valle_sample / valle_cfg_combine against the reference's own sampler outputs (samplers_kat)."""
     m = hip_model("tiny")

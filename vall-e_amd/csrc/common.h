@@ -97,6 +97,10 @@ struct SampleArgs {
 };
 int valle_sample_launch(const SampleArgs& a, int rows, hipStream_t s);
 
+// dense QKV projection with RoPE applied in the epilogue (gemm.hip; internal epilogue code, bf16, head_dim 64):
+// qkv[m][0:2d] rotated by position pos[m] exactly as valle_rope_kv does, qkv[m][2d:3d] stored as is
+#define GEMM_EPI_ROPE 5
+
 #define DEC_EPI_QKV 10
 // wave-streaming decode linears (dec_linear.hip): activations in fragment order, norm weight folded into W
 struct DecWArgs {

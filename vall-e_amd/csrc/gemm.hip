@@ -19,7 +19,45 @@
 template <typename T, int EPI, int NI = 4, int MJ = 4>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[NI][MJ], int nw0, int mw0, int fr, int fq,
                                               const void* __restrict__ bias, const T* resid, void* Cout,
-                                              int M, int N, int ldc) {
+                                              int M, int N, int ldc, const float* rope_rows = nullptr) {
+    if constexpr (EPI == GEMM_EPI_ROPE) {
+        // QKV projection: q and k columns are pair-interleaved, a lane's 4 columns are two RoPE pairs
+        // (arch/llama.py:48-61); same arithmetic as rope_kv_kernel: operands rounded to the storage type, the two
+        // products rounded separately.  rope_rows (LDS): the (cos, sin) row of each of the workgroup's 128 positions,
+        // [row][68 floats], staged by the kernel -- a row serves every head, so it is fetched once per workgroup.
+        T* C = (T*)Cout;
+        typedef T vec4 __attribute__((ext_vector_type(4)));
+        const int d = N / 3;
+        f32x4 rp[NI][MJ];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MJ; ++j)
+                rp[i][j] = *reinterpret_cast<const f32x4*>(rope_rows + ((mw0 & 127) + j * 16 + fr) * 68 + i * 16 + fq * 4);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int nb = nw0 + i * 16 + fq * 4;
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) {
+                const int m = mw0 + j * 16 + fr;
+                if (m >= M || nb >= N) continue;
+                vec4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(acc[i][j][r]);
+                if (nb < 2 * d) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const float cs = to_f32<T>(from_f32<T>(rp[i][j][2 * q])), sn = to_f32<T>(from_f32<T>(rp[i][j][2 * q + 1]));
+                        const float u = to_f32<T>(o[2 * q]), w = to_f32<T>(o[2 * q + 1]);
+                        o[2 * q] = from_f32<T>(__fadd_rn(__fmul_rn(u, cs), __fmul_rn(-w, sn)));
+                        o[2 * q + 1] = from_f32<T>(__fadd_rn(__fmul_rn(w, cs), __fmul_rn(u, sn)));
+                    }
+                }
+                *reinterpret_cast<vec4*>(C + (size_t)m * ldc + nb) = o;
+            }
+        }
+        return;
+    }
     // epilogue: lane holds n = nb + 0..3 (consecutive) for one m
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -207,6 +245,19 @@ __global__ __launch_bounds__(256) void gemm_glds_bf16_kernel(const bf16* __restr
             aoff[i][hf] = ra * 128 + (((hf * 4 + fq) ^ (ra & 7)) << 4);
             boff[i][hf] = rb * 128 + (((hf * 4 + fq) ^ (rb & 7)) << 4);
         }
+    // EPI_ROPE: the (cos, sin) rows of this workgroup's 128 positions are requested now (8 x 16 B per thread), kept in
+    // registers through the main loop and handed to the epilogue through LDS
+    [[maybe_unused]] f32x4 rrow[8];
+    if constexpr (EPI == GEMM_EPI_ROPE) {
+        const int32_t* pos = reinterpret_cast<const int32_t*>(resid);
+        const float* tab = reinterpret_cast<const float*>(bias);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int idx = tid + 256 * t;                 // row = idx / 16, 16-byte piece = idx % 16
+            int m = m0 + (idx >> 4); m = m < M ? m : M - 1;
+            rrow[t] = *reinterpret_cast<const f32x4*>(tab + (size_t)pos[m] * 64 + (idx & 15) * 4);
+        }
+    }
     const int nt = K / 64;
     stage(0, 0);
     for (int kt = 0; kt < nt; ++kt) {
@@ -233,7 +284,19 @@ __global__ __launch_bounds__(256) void gemm_glds_bf16_kernel(const bf16* __restr
             __builtin_amdgcn_s_setprio(0);
         }
     }
-    gemm_epilogue<bf16, EPI>(acc, n0 + wn * 64, m0 + wm * 64, fr, fq, bias, resid, Cout, M, N, ldc);
+    if constexpr (EPI == GEMM_EPI_ROPE) {
+        float* rope_rows = reinterpret_cast<float*>(&lds[0][0][0]);     // 128 x 68 floats = 34 KB of the 64 KB
+        __syncthreads();                                   // the last tile has been read by every wave
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int idx = tid + 256 * t;
+            *reinterpret_cast<f32x4*>(rope_rows + (idx >> 4) * 68 + (idx & 15) * 4) = rrow[t];
+        }
+        __syncthreads();
+        gemm_epilogue<bf16, EPI>(acc, n0 + wn * 64, m0 + wm * 64, fr, fq, bias, resid, Cout, M, N, ldc, rope_rows);
+    } else {
+        gemm_epilogue<bf16, EPI>(acc, n0 + wn * 64, m0 + wm * 64, fr, fq, bias, resid, Cout, M, N, ldc);
+    }
 }
 
 // Narrow-N variant (o_proj / down_proj, N = d_model): 64(n) x 128(m) tile, the 4 waves side by side along m
@@ -456,6 +519,18 @@ static int gemm_glds_dispatch(const void* A, const void* W, const void* bias, co
         default: valle_set_error("valle_gemm: unknown epilogue %d", epi); return VALLE_E_ARG;
     }
 #undef GLDS_CASE
+    VALLE_LAUNCH_CHECK();
+    return VALLE_OK;
+}
+
+extern "C" int valle_gemm_qkv_rope(const void* A, const void* Wqkv, const float* rope, const int32_t* pos, void* qkv,
+                                   int M, int d, int K, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    VALLE_REQUIRE(A && Wqkv && rope && pos && qkv, VALLE_E_ARG, "valle_gemm_qkv_rope: null pointer");
+    VALLE_REQUIRE(d % 64 == 0 && K % 64 == 0 && M >= 64, VALLE_E_UNSUPPORTED, "valle_gemm_qkv_rope: M=%d d=%d K=%d", M, d, K);
+    const int N = 3 * d;
+    dim3 grid(ceil_div(N, 128), ceil_div(M, 128));
+    gemm_glds_bf16_kernel<GEMM_EPI_ROPE><<<grid, 256, 0, s>>>((const bf16*)A, (const bf16*)Wqkv, rope, (const bf16*)pos, qkv, M, N, K, N);
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
 }

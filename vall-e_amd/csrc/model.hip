@@ -154,10 +154,15 @@ extern "C" int valle_forward_dense(valle_model* m, const int32_t* emb_idx, const
     for (int l = 0; l < c.n_layers; ++l) {
         const valle_layer_weights& w = m->layers[l];
         RUN(valle_rmsnorm(x, w.ln1, h, M, d, c.rms_eps, dt, s));
-        RUN(valle_gemm(h, w.w_qkv, nullptr, nullptr, qkv, M, 3 * d, d, 3 * d, VALLE_EPI_STORE, dt, s));
         void* kc = kcache ? (char*)kcache + (size_t)l * cache_layer_stride * es : nullptr;
         void* vc = vcache ? (char*)vcache + (size_t)l * cache_layer_stride * es : nullptr;
-        RUN(valle_rope_kv(qkv, pos, m->rope, cu_seqlens, B, M, H, Dh, kc, vc, cache_T, cache_slot, cache_pos0, dt, s));
+        if (dt == VALLE_BF16 && !kcache && Dh == 64 && d % 64 == 0 && M >= 64) {
+            // passes without a KV cache (NAR levels, NAR-len steps): RoPE rides in the projection's epilogue
+            RUN(valle_gemm_qkv_rope(h, w.w_qkv, m->rope, pos, qkv, M, d, d, s));
+        } else {
+            RUN(valle_gemm(h, w.w_qkv, nullptr, nullptr, qkv, M, 3 * d, d, 3 * d, VALLE_EPI_STORE, dt, s));
+            RUN(valle_rope_kv(qkv, pos, m->rope, cu_seqlens, B, M, H, Dh, kc, vc, cache_T, cache_slot, cache_pos0, dt, s));
+        }
         RUN(valle_attn_prefill(qkv, h, cu_seqlens, B, M, max_T, H, Dh, causal, dt, s));
         RUN(valle_gemm(h, w.w_o, nullptr, x, x, M, d, d, d, VALLE_EPI_RESID, dt, s));
         RUN(valle_rmsnorm(x, w.ln2, h, M, d, c.rms_eps, dt, s));
