@@ -526,36 +526,37 @@ __global__ __launch_bounds__(1024) void cfg_combine_kernel(float* __restrict__ p
         oa = 0; ob = 0;
         for (int w = 0; w < 16; ++w) { oa += red[0][w]; ob += red[1][w]; }
     };
+    // one pass for the statistics (sums and sums of squares in double: n <= a few 1e5 values of O(10), the cancellation in
+    // sum(x^2) - sum(x)^2 / n costs ~1e-10 relative), one pass to write; rows x columns, no per-element division
     float factor = 1.0f;
     if (rescale > 0.f) {
-        double sp = 0, sm = 0;
-        for (long e = threadIdx.x; e < n; e += 1024) {
-            const size_t o = (size_t)(r0 + e / vocab) * ld + e % vocab;
-            const float p = pos[o], q = neg[o];
-            sp += p; sm += q + (p - q) * strength;
+        double sp = 0, sm = 0, qp = 0, qm = 0;
+        for (int r = r0; r < r1; ++r) {
+            const float* pr = pos + (size_t)r * ld;
+            const float* nr = neg + (size_t)r * ld;
+            for (int v = threadIdx.x; v < vocab; v += 1024) {
+                const float p = pr[v], q = nr[v];
+                const double sd = (double)(q + (p - q) * strength);
+                sp += p; qp += (double)p * p; sm += sd; qm += sd * sd;
+            }
         }
-        double tp, tm;
+        double tp, tm, tqp, tqm;
         block_sum2(sp, sm, tp, tm);
-        const double mp = tp / n, mm = tm / n;
-        double vp = 0, vm = 0;
-        for (long e = threadIdx.x; e < n; e += 1024) {
-            const size_t o = (size_t)(r0 + e / vocab) * ld + e % vocab;
-            const float p = pos[o], q = neg[o];
-            const double dp = p - mp, dm = (double)(q + (p - q) * strength) - mm;
-            vp += dp * dp; vm += dm * dm;
-        }
-        double tvp, tvm;
-        block_sum2(vp, vm, tvp, tvm);
-        const float sdp = (float)sqrt(tvp / (n - 1)), sdm = (float)sqrt(tvm / (n - 1));
+        block_sum2(qp, qm, tqp, tqm);
+        const double vp = (tqp - tp * tp / n) / (n - 1), vm = (tqm - tm * tm / n) / (n - 1);
+        const float sdp = (float)sqrt(vp > 0 ? vp : 0), sdm = (float)sqrt(vm > 0 ? vm : 0);
         factor = rescale * (sdp / sdm) + (1.0f - rescale);
     }
     __syncthreads();
-    for (long e = threadIdx.x; e < n; e += 1024) {
-        const size_t o = (size_t)(r0 + e / vocab) * ld + e % vocab;
-        const float p = pos[o], q = neg[o];
-        float s = q + (p - q) * strength;
-        if (rescale > 0.f) s = s * factor;
-        pos[o] = s;
+    for (int r = r0; r < r1; ++r) {
+        float* pr = pos + (size_t)r * ld;
+        const float* nr = neg + (size_t)r * ld;
+        for (int v = threadIdx.x; v < vocab; v += 1024) {
+            const float p = pr[v], q = nr[v];
+            float s = q + (p - q) * strength;
+            if (rescale > 0.f) s = s * factor;
+            pr[v] = s;
+        }
     }
     (void)stat;
 }
