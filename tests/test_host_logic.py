@@ -197,14 +197,22 @@ def test_len_task_plan_and_inputs():
         plain.plan(phns, langs, proms, [None] * 3, 0, task="len", len_list=seqs)
 
 
+def tokenizer_spec(kat):
+    """The tokenizer description (the layout of a Hugging Face tokenizer.json) from the fixture's tables."""
+    return {"model": {"type": "BPE", "vocab": kat["vocab"], "merges": kat["merges"], "unk_token": kat["unk_token"]},
+            "added_tokens": kat["added_tokens"], "normalizer": None, "pre_tokenizer": None,
+            "post_processor": {"type": "TemplateProcessing", "single": kat["template_single"],
+                               "special_tokens": kat["template_special_tokens"]}}
+
+
 def test_phoneme_tokenizer_known_answers():
     """utils/tokenizer.py (BPE restatement) against the ids of the library the reference tokenizes with, on the
     reference's own tokenizer.json; includes the phoneme string bundled with data/qnt.enc (BASELINE configs[0])."""
     import json
     from vall_e_amd.utils.tokenizer import PhonemeTokenizer
     from vall_e_amd.synth import QNT_ENC_PHONEME_IDS
-    tok = PhonemeTokenizer.from_file(ROOT / "tests" / "golden" / "tokenizer.json")
     kat = json.loads((ROOT / "tests" / "golden" / "tokenizer_kat.json").read_text(encoding="utf-8"))
+    tok = PhonemeTokenizer(tokenizer_spec(kat))
     assert len(kat["cases"]) == 200
     for text, ids in kat["cases"]:
         assert tok.encode(text) == ids, text
@@ -223,7 +231,9 @@ def test_tts_text_front_end_ids():
     tts.tokenizer = None
     with pytest.raises(RuntimeError, match="tokenizer"):
         tts.encode_text("ðə")
-    tts.load_tokenizer(ROOT / "tests" / "golden" / "tokenizer.json")
+    import json
+    from vall_e_amd.utils.tokenizer import PhonemeTokenizer
+    tts.tokenizer = PhonemeTokenizer(tokenizer_spec(json.loads((ROOT / "tests" / "golden" / "tokenizer_kat.json").read_text(encoding="utf-8"))))
     ids = tts.encode_text("wˈʌns ɐɡˈɛn, ˈɛksələnt wˈɜːk.")
     assert ids.dtype == torch.int16 and ids.tolist() == QNT_ENC_PHONEME_IDS
     t = torch.tensor([1, 5, 2])
