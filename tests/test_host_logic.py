@@ -223,7 +223,7 @@ def test_phoneme_tokenizer_known_answers():
     assert tok.get_vocab()["<bos>"] == 1
 
 
-def test_tts_text_front_end_ids():
+def test_tts_text_front_end_ids(tmp_path):
     """TTS.encode_text / encode_lang (inference.py:111-137) on phoneme strings; tensors pass through."""
     from vall_e_amd.inference import TTS
     from vall_e_amd.synth import QNT_ENC_PHONEME_IDS
@@ -232,8 +232,9 @@ def test_tts_text_front_end_ids():
     with pytest.raises(RuntimeError, match="tokenizer"):
         tts.encode_text("ðə")
     import json
-    from vall_e_amd.utils.tokenizer import PhonemeTokenizer
-    tts.tokenizer = PhonemeTokenizer(tokenizer_spec(json.loads((ROOT / "tests" / "golden" / "tokenizer_kat.json").read_text(encoding="utf-8"))))
+    spec = tokenizer_spec(json.loads((ROOT / "tests" / "golden" / "tokenizer_kat.json").read_text(encoding="utf-8")))
+    (tmp_path / "tokenizer.json").write_text(json.dumps(spec, ensure_ascii=False), encoding="utf-8")
+    tts.load_tokenizer(tmp_path / "tokenizer.json")                                # the file layout the reference ships
     ids = tts.encode_text("wˈʌns ɐɡˈɛn, ˈɛksələnt wˈɜːk.")
     assert ids.dtype == torch.int16 and ids.tolist() == QNT_ENC_PHONEME_IDS
     t = torch.tensor([1, 5, 2])
