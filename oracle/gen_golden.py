@@ -20,6 +20,7 @@ Scenarios (names = file stems under tests/golden/):
   tiny_cfg          tiny model: AR + NAR with cfg_strength > 0
   tiny_narlen       tiny model: NAR-len demasking (max_steps 6) + NAR levels
   tiny_noncausal    tiny model with noncausal_masks=True: tiny_nc_ar_nar (AR + NAR levels), tiny_nc_narlen
+  tiny_prefix_ctx   tiny model: AR of a second line with the first line as rolling prefix_context
   tiny_len          tiny model with the `len` capability: duration prediction (task "len"), per-step logits
   full_b1           BASELINE configs[0]: full model, qnt.enc prompt, 19 phonemes, AR 24 + NAR
   full_b3           full model, ragged B=3, AR 12 + NAR
@@ -484,6 +485,29 @@ def scen_tiny_noncausal():
     narlen_scenario("tiny_nc_narlen", "tiny_nc", phns, proms, langs, lens=[17, 23], max_steps=5)
 
 
+def scen_tiny_prefix_context():
+    """Rolling context (inference.py:575-584 -> ar_nar.py:736-742, :886-888): the second line's AR call gets the first
+    line's phonemes and codes as prefix_context."""
+    ref = rh.load_reference()
+    model, mcfg = get_ref_model("tiny")
+    phns1, proms, langs = synth_batch(91, 2, n_phn=9, n_prom=14, ragged=True)
+    phns2, _, _ = synth_batch(92, 2, n_phn=11, n_prom=14, ragged=True)
+    with Recorder(ref) as rec:
+        codes1 = run_ar(model, phns1, proms, langs, max_duration=10, temperature=0.0)
+        full1 = run_nar(model, phns1, proms, langs, codes1, temperature=0.0)
+        n1 = len(rec.calls)
+        ctx = ([p.clone() for p in phns1], [f.clone() for f in full1], [int(f.shape[0]) for f in full1])
+        codes2 = run_ar(model, phns2, proms, langs, max_duration=12, temperature=0.0, prefix_context=ctx)
+    gap = min(top2_gap(r) for c in rec.calls[:10] + rec.calls[n1:] for r in c["logits"])
+    if gap <= MIN_GAP:
+        raise RuntimeError(f"tiny_prefix_ctx: top-2 margin {gap:.2e} too small")
+    d = input_arrays(phns1, proms, langs)
+    d.update(pack_list("phn2", phns2)), d.update(pack_list("full1", full1)), d.update(pack_list("codes2", codes2))
+    d["steps1"], d["steps2"], d["min_gap"] = np.int64(10), np.int64(12), np.float64(gap)
+    d["first_logits2"] = torch.stack(rec.calls[n1]["logits"])
+    save("tiny_prefix_ctx", **d)
+
+
 def scen_full_b1():
     ref = rh.load_reference()
     phns, proms, langs = qnt_inputs()
@@ -535,6 +559,7 @@ SCENARIOS = {
     "tiny_cfg": scen_tiny_cfg,
     "tiny_narlen": scen_tiny_narlen,
     "tiny_len": scen_tiny_len,
+    "tiny_prefix_context": scen_tiny_prefix_context,
     "tiny_noncausal": scen_tiny_noncausal,
     "full_b1": scen_full_b1,
     "full_b3": scen_full_b3,

@@ -454,13 +454,21 @@ class Oracle:
         return (out, kept, seqs) if return_logits else out
 
     # -- AR (ar_nar.py:588-890, tts task) ---------------------------------------------
-    def ar(self, phns, proms, langs, *, max_duration=500, use_cache=False, return_logits=False, generator=None, **kw):
+    def ar(self, phns, proms, langs, *, max_duration=500, use_cache=False, return_logits=False, generator=None,
+           prefix_context=None, **kw):
+        """prefix_context = (texts, resps, lens) of earlier lines (ar_nar.py:736-742): their phonemes are spliced in
+        front of this line's (dropping the inner <eos><bos>), their level-0 codes start the sequence, and the first
+        lens[i] tokens are cut off the result (:886-888)."""
         kw = convert_kwargs(dict(kw), "ar_")
         temperature = kw.get("temperature", 1.0)
         cfg_strength = kw.get("cfg_strength", 0.0)
         cfg_rescale = kw.pop("cfg_rescale", 0.7)
         B = len(phns)
         seqs = [torch.zeros(0, dtype=torch.int64) for _ in range(B)]
+        if prefix_context is not None:
+            prefix_text, prefix_resps, prefix_lens = prefix_context
+            phns = [torch.cat([p[:-1].long(), t[1:].long()]) for p, t in zip(prefix_text, phns)]
+            seqs = [(r if r.dim() == 1 else r[:, 0]).long() for r in prefix_resps]
         stopped = [False] * B
         null_phn = [torch.tensor([1, 2]) for _ in range(B)]
         last_logits = []
@@ -486,9 +494,10 @@ class Oracle:
             if all(stopped):
                 break
         out = []
-        for s in seqs:
+        for i, s in enumerate(seqs):
             hit = (s == self.stop_token).nonzero()
-            out.append(s if len(hit) == 0 else s[: int(hit.min())])
+            s = s if len(hit) == 0 else s[: int(hit.min())]
+            out.append(s[int(prefix_context[2][i]):] if prefix_context is not None else s)
         return (out, last_logits) if return_logits else out
 
     def _forward_cached(self, phns, langs, proms, seqs, kv, first):

@@ -376,6 +376,30 @@ def test_tiny_noncausal_masks_codes_identical(gpu_device):
         assert rel_l2(g, w.float()) < 4e-2
 
 
+def test_tiny_prefix_context_and_tts_inference(gpu_device):
+    """Rolling context: AR with prefix_context (ar_nar.py:736-742, :886-888) gives the reference's codes; TTS.inference
+    (inference.py:477-584: line by line, context_history previous lines as prefix) returns the same codes per line."""
+    from vall_e_amd.inference import TTS
+    z = load_golden("tiny_prefix_ctx")
+    phns1, proms, langs = golden_inputs(z)
+    B = len(phns1)
+    phns2 = [torch.from_numpy(z[f"phn2_{i}"]) for i in range(B)]
+    full1 = [torch.from_numpy(z[f"full1_{i}"].astype(np.int64)) for i in range(B)]
+    m = hip_model("tiny")
+    ctx = (phns1, full1, [int(f.shape[0]) for f in full1])
+    codes2 = m(task_list=["tts"] * B, phns_list=phns2, proms_list=proms, lang_list=langs, max_duration=int(z["steps2"]),
+               temperature=0.0, prefix_context=ctx)
+    for b in range(B):
+        np.testing.assert_array_equal(codes2[b].cpu().numpy(), z[f"codes2_{b}"])
+    tts = TTS(config=model_cfg("tiny"), device="cuda:0", dtype=torch.float32, state_dict=synth_weights("tiny"))
+    for b in range(B):
+        lines = tts.inference([phns1[b], phns2[b]], proms[b], language=langs[b], context_history=1, temperature=0.0,
+                              max_duration=[int(z["steps1"]), int(z["steps2"])])
+        np.testing.assert_array_equal(lines[0].cpu().numpy(), z[f"full1_{b}"])
+        np.testing.assert_array_equal(lines[1][:, 0].cpu().numpy(), z[f"codes2_{b}"])
+        assert lines[1].shape[1] == 8
+
+
 def test_full_bf16_logits_within_tolerance(gpu_device):
     """bf16 tolerance (stated): rel-L2 <= 4e-2 against the reference's bf16 logits; the reference's
     own bf16 run sits 2.2e-2 from its fp32 run on these rows (see test_oracle_vs_golden)."""

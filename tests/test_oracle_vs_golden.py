@@ -214,6 +214,29 @@ def test_tiny_noncausal_masks():
     assert any((other[b].numpy() != z[f"nar_codes_{b}"]).any() for b in range(len(phns)))
 
 
+def _prefix_ctx_inputs(z):
+    phns1, proms, langs = golden_inputs(z)
+    B = len(phns1)
+    phns2 = [torch.from_numpy(z[f"phn2_{i}"]) for i in range(B)]
+    full1 = [torch.from_numpy(z[f"full1_{i}"].astype(np.int64)) for i in range(B)]
+    return phns1, phns2, proms, langs, full1
+
+
+def test_tiny_prefix_context():
+    """Rolling context (ar_nar.py:736-742, :886-888): line 1 reproduces, then line 2's AR with line 1 as prefix."""
+    z = load_golden("tiny_prefix_ctx")
+    phns1, phns2, proms, langs, full1 = _prefix_ctx_inputs(z)
+    o = make_oracle("tiny")
+    codes1 = o.ar(phns1, proms, langs, max_duration=int(z["steps1"]), temperature=0.0)
+    for b in range(len(phns1)):
+        np.testing.assert_array_equal(codes1[b].numpy(), z[f"full1_{b}"][:, 0])
+    ctx = (phns1, full1, [int(f.shape[0]) for f in full1])
+    codes2, logits = o.ar(phns2, proms, langs, max_duration=int(z["steps2"]), temperature=0.0, prefix_context=ctx, return_logits=True)
+    for b in range(len(phns1)):
+        np.testing.assert_array_equal(codes2[b].numpy(), z[f"codes2_{b}"])
+    assert_close(logits[0], z["first_logits2"], 5e-4, 5e-4)
+
+
 def test_full_b1_configs0():
     """BASELINE.json configs[0]: repo-default model, data/qnt.enc prompt, greedy AR + NAR."""
     _ar_nar("full", "full_b1")

@@ -152,6 +152,53 @@ class TTS:
         return modality
 
     @torch.inference_mode()
+    def inference(self, text, references, language="auto", text_language=None, task="tts", out_path=None, play=False,
+                  **sampling_kwargs):
+        """inference.py:361-597, the serial line-by-line path, for ``task="tts"``: every line (a list of phoneme strings
+        / id tensors, or one string split at newlines -- sentence splitting and language detection belong to the text
+        front end) runs AR then NAR, or len -> NAR-len; with ``context_history`` = n > 0 the AR call of a line gets the
+        previous n lines' phonemes and codes as ``prefix_context`` (:575-584).  Returns the list of per-line (R, 8)
+        code tensors the reference hands to ``qnt.decode_to_file`` one after the other (:587).  ``max_duration`` may be
+        a list (one value per line)."""
+        if task != "tts":
+            raise NotImplementedError(f"task {task!r}: TTS.inference is built for 'tts'")
+        for k in ("input_prompt_length", "seed", "tqdm", "use_lora", "dtype", "amp", "phonemize", "voice_convert", "split_text_by"):
+            sampling_kwargs.pop(k, None)
+        modality = self.modality(sampling_kwargs.pop("modality", "auto"))
+        duration_padding = sampling_kwargs.pop("duration_padding", 1.05)
+        context_history = int(sampling_kwargs.pop("context_history", 0))
+        max_duration = sampling_kwargs.pop("max_duration", None)
+        lines = text.split("\n") if isinstance(text, str) else list(text)
+        lines = [l for l in lines if not isinstance(l, str) or l.strip()] or [""]
+        prom = references
+        lang = self.encode_lang(language) if isinstance(language, str) else language
+        prefix_context, history, out = None, [], []
+        for n, line in enumerate(lines):
+            phns = self.encode_text(line)
+            kw = dict(phns_list=[phns], proms_list=[prom], lang_list=[lang])
+            per_line = dict(sampling_kwargs)
+            if max_duration is not None:
+                per_line["max_duration"] = max_duration[n] if isinstance(max_duration, (list, tuple)) else max_duration
+            if modality == "nar-len":
+                lens = self.model(**kw, task_list=["len"], max_duration=5)
+                lens = [int(max(l, 75) * duration_padding) for l in lens]         # inference.py:535-538 (75 frames per second)
+                if prefix_context is not None:
+                    per_line["prefix_context"] = prefix_context
+                resps = self.model(**kw, task_list=["tts"], len_list=lens, **per_line)
+            else:
+                extra = {"prefix_context": prefix_context} if prefix_context is not None else {}
+                resps = self.model(**kw, task_list=["tts"], **per_line, **extra)
+                resps = self.model(**kw, task_list=["tts"], resps_list=resps, **per_line)
+            r = resps[0]
+            out.append(r)
+            if context_history > 0:                                               # inference.py:575-584
+                history.append((phns, r, int(r.shape[0])))
+                last = history[-context_history:]
+                prefix_context = ([torch.cat([torch.as_tensor(x[0]) for x in last])], [torch.cat([x[1] for x in last])],
+                                  [sum(x[2] for x in last)])
+        return out
+
+    @torch.inference_mode()
     def batched_inference(self, texts, references=None, languages=None, text_languages=None, out_paths=None,
                           len_list=None, rank=0, world_size=1, **sampling_kwargs):
         """-> list of (R_i, 8) code tensors for THIS rank's utterances plus their indices when
