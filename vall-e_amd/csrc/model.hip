@@ -1,7 +1,6 @@
 // Model-level orchestration: one dense pass (Base.forward, models/base.py:1184-1278) and the
 // KV-cache AR decode loop (models/ar_nar.py:748-848).  Host code only enqueues kernels.
 #include "common.h"
-#include <stdlib.h>
 
 extern "C" int valle_attn_prefill(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int M, int max_T,
                                   int H, int Dh, int causal, int dtype, void* stream) {
