@@ -506,6 +506,9 @@ def scen_tiny_prefix_context():
     d["steps1"], d["steps2"], d["min_gap"] = np.int64(10), np.int64(12), np.float64(gap)
     d["first_logits2"] = torch.stack(rec.calls[n1]["logits"])
     save("tiny_prefix_ctx", **d)
+    # the same rolling context through the NAR-len path (ar_nar.py:321-325, :391-392), then the NAR levels
+    narlen_scenario("tiny_prefix_narlen", "tiny", phns2, proms, langs, lens=[13, 16], max_steps=5,
+                    prefix_context=([p.clone() for p in phns1], [f.clone() for f in full1], [int(f.shape[0]) for f in full1]))
 
 
 def scen_full_b1():

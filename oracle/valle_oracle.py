@@ -557,6 +557,11 @@ class Oracle:
         remask = kw.get("sampling_scores_remask", False)
         lens = [clamp(int(l), min_len, max_len) for l in lens]
         B = len(lens)
+        prefix = [torch.zeros(0, dtype=torch.int64) for _ in range(B)]
+        prefix_context = kw.pop("prefix_context", None)
+        if prefix_context is not None:                                   # ar_nar.py:321-325, :391-392
+            phns = [torch.cat([p[:-1].long(), t[1:].long()]) for p, t in zip(prefix_context[0], phns)]
+            prefix = [(r if r.dim() == 1 else r[:, 0]).long() for r in prefix_context[1]]
         resps = [torch.full((n,), self.mask_token, dtype=torch.int64) for n in lens]
         scores = [torch.ones(n, dtype=torch.float32) for n in lens]
         null_phn = [torch.tensor([1, 2]) for _ in range(B)]
@@ -568,9 +573,10 @@ class Oracle:
             resps = [r.scatter(0, i, self.mask_token) for r, i in zip(resps, idx)]
             is_masked = [r == self.mask_token for r in resps]
             temp = temperature * (1.0 - float(t)) if annealed else temperature
-            logits = self.forward(self._plans(phns, langs, proms, resps, 0, timestep=True), rows=lens)
+            inp = [torch.cat([p, r]) for p, r in zip(prefix, resps)]
+            logits = self.forward(self._plans(phns, langs, proms, inp, 0, timestep=True), rows=lens)
             if cfg_strength > 0:
-                null = self.forward(self._plans(null_phn, langs, None, resps, 0, timestep=True), rows=lens)
+                null = self.forward(self._plans(null_phn, langs, None, inp, 0, timestep=True), rows=lens)
                 logits = cfg_combine(logits, null, cfg_strength, lens, cfg_rescale)
             # the reference samples twice on the SAME tensors; in-place processors (rep-pen,
             # top-k/top-p) therefore act twice before the "unfiltered" score pass
@@ -585,4 +591,5 @@ class Oracle:
     def nar_len(self, phns, proms, langs, lens, **kw):
         """AR_NAR.forward with len_list (ar_nar.py:485-496 then the level loop)."""
         level0 = self.nar_masked(phns, proms, langs, lens, **dict(kw))
+        kw.pop("prefix_context", None)                                   # the level loop runs on this line alone
         return self.nar(phns, proms, langs, level0, **kw)

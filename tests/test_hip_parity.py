@@ -391,6 +391,11 @@ def test_tiny_prefix_context_and_tts_inference(gpu_device):
                temperature=0.0, prefix_context=ctx)
     for b in range(B):
         np.testing.assert_array_equal(codes2[b].cpu().numpy(), z[f"codes2_{b}"])
+    zn = load_golden("tiny_prefix_narlen")                               # the same context through NAR-len + NAR levels
+    out = m(task_list=["tts"] * B, phns_list=phns2, proms_list=proms, lang_list=langs, len_list=[int(x) for x in zn["lens"]],
+            max_steps=int(zn["max_steps"]), temperature=0.0, prefix_context=ctx)
+    for b in range(B):
+        np.testing.assert_array_equal(out[b].cpu().numpy(), zn[f"codes_{b}"])
     tts = TTS(config=model_cfg("tiny"), device="cuda:0", dtype=torch.float32, state_dict=synth_weights("tiny"))
     for b in range(B):
         lines = tts.inference([phns1[b], phns2[b]], proms[b], language=langs[b], context_history=1, temperature=0.0,
@@ -398,6 +403,34 @@ def test_tiny_prefix_context_and_tts_inference(gpu_device):
         np.testing.assert_array_equal(lines[0].cpu().numpy(), z[f"full1_{b}"])
         np.testing.assert_array_equal(lines[1][:, 0].cpu().numpy(), z[f"codes2_{b}"])
         assert lines[1].shape[1] == 8
+
+
+def test_edge_shapes_match_oracle(gpu_device):
+    """Smallest and most ragged shapes: no prompt, one-phoneme text, one AR step, one-frame NAR, batch of one."""
+    m, o = hip_model("tiny"), oracle("tiny")
+    g = torch.Generator().manual_seed(5)
+    cases = [
+        ([torch.tensor([1, 7, 2])], None, [torch.tensor([0])], 1),                                   # no prompt, 1 step
+        ([torch.tensor([1, 2]), torch.tensor([1, 9, 33, 4, 2])], [torch.randint(0, 1024, (1, 8), generator=g), torch.randint(0, 1024, (37, 8), generator=g)],
+         [torch.tensor([0]), torch.tensor([1])], 3),                                                 # 1-frame prompt next to a long one
+    ]
+    for phns, proms, langs, steps in cases:
+        B = len(phns)
+        kw = dict(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs)
+        codes = m(**kw, max_duration=steps, temperature=0.0)
+        want = o.ar(phns, proms, langs, max_duration=steps, temperature=0.0)
+        for b in range(B):
+            np.testing.assert_array_equal(codes[b].cpu().numpy(), want[b].numpy())
+        full = m(**kw, resps_list=[c.clone() for c in codes], temperature=0.0)
+        wfull = o.nar(phns, proms, langs, want, temperature=0.0)
+        for b in range(B):
+            assert full[b].shape == (steps, 8)
+            np.testing.assert_array_equal(full[b].cpu().numpy(), wfull[b].numpy())
+    # bf16, batch of one, a single cached step after the prefill
+    mb = hip_model("tiny", torch.bfloat16)
+    out = mb(task_list=["tts"], phns_list=[torch.tensor([1, 7, 2])], proms_list=[torch.randint(0, 1024, (5, 8), generator=g)],
+             lang_list=[torch.tensor([0])], max_duration=2, temperature=0.0)
+    assert out[0].shape == (2,)
 
 
 def test_full_bf16_logits_within_tolerance(gpu_device):

@@ -237,6 +237,19 @@ def test_tiny_prefix_context():
     assert_close(logits[0], z["first_logits2"], 5e-4, 5e-4)
 
 
+def test_tiny_prefix_context_narlen():
+    """The same rolling context through NAR-len (ar_nar.py:321-325, :391-392): prefix codes precede the masked response
+    in both the conditional and the null pass; the NAR levels after it run on the line alone."""
+    z, c = load_golden("tiny_prefix_narlen"), load_golden("tiny_prefix_ctx")
+    phns2, proms, langs = golden_inputs(z)
+    phns1, _, _, _, full1 = _prefix_ctx_inputs(c)
+    o = make_oracle("tiny")
+    out = o.nar_len(phns2, proms, langs, [int(x) for x in z["lens"]], max_steps=int(z["max_steps"]), temperature=0.0,
+                    prefix_context=(phns1, full1, [int(f.shape[0]) for f in full1]))
+    for b in range(len(phns2)):
+        np.testing.assert_array_equal(out[b].numpy(), z[f"codes_{b}"])
+
+
 def test_full_b1_configs0():
     """BASELINE.json configs[0]: repo-default model, data/qnt.enc prompt, greedy AR + NAR."""
     _ar_nar("full", "full_b1")

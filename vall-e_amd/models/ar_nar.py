@@ -364,7 +364,8 @@ class AR_NAR(Base):
         start_noise, end_noise = kw.get("denoise_start", 0.0), kw.get("denoise_end", 1.0)
         max_steps = math.floor(max_steps * (end_noise - start_noise))
         remasking = kw.get("sampling_scores_remask", False)
-        for k in ("sampling_scores_masked_only", "vc_list", "prefix_context"):
+        prefix_context = kw.pop("prefix_context", None)
+        for k in ("sampling_scores_masked_only", "vc_list"):
             if kw.get(k):
                 raise NotImplementedError(f"{k} is not built on the HIP path")
         if start_noise > 0.0:
@@ -385,6 +386,11 @@ class AR_NAR(Base):
         # the sequence layout does not change between demasking steps: both plans are built and uploaded once, and
         # every step patches the response rows' embedding ids with the current codes on the device
         zeros = [np.zeros(n, np.int64) for n in lens]
+        if prefix_context is not None:                                        # ar_nar.py:321-325, :391-392: earlier lines'
+            prefix_text, prefix_resps, _ = prefix_context                     # phonemes and level-0 codes in front, both passes
+            phns_list = [torch.cat([torch.as_tensor(p)[:-1].cpu(), torch.as_tensor(t)[1:].cpu()]) for p, t in zip(prefix_text, phns_list)]
+            pre = _host_codes(list(prefix_resps))
+            zeros = [np.concatenate([(p if p.ndim == 1 else p[:, 0]).astype(np.int64), z]) for p, z in zip(pre, zeros)]
         plan = self.plan(phns_list, lang_list, proms_list, zeros, 0, timestep=True)
         rows, roff = self.tail_rows(plan, lens)
         pdev = self.upload_plan(plan, rows)
