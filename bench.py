@@ -201,6 +201,11 @@ def main():
         dense = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "what": f"7 NAR levels, {B} x {T} tokens each, host time included",
                  "ms": round(nar_ms, 2)}
+        mf = ROOT / "profiles" / "r1_pmc_mfma_dense_gemms.json"
+        if mf.exists():     # MFMA pipe utilisation of the four layer GEMMs from the PMC pass committed under profiles/
+            dense["mfma_busy_frac_pmc"] = {k.split("(")[0].replace("void ", ""): round(v["mfma_busy_frac"], 3)
+                                           for k, v in json.loads(mf.read_text()).items()}
+            dense["mfma_busy_source"] = f"profiles/{mf.name} (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 256 CUs x 4 SIMDs), tools/micro_gemm)"
     if rank == 0:
         line = {
             "metric": "RVQ frames/sec (all levels)", "value": round(frames / elapsed, 2), "unit": "frames/s",
