@@ -10,8 +10,9 @@
 // fragment).  The <= 16 activation rows are kept in the same "fragment order" by every producer on the
 // decode path, so the B operand is 1 KiB-contiguous too and needs no LDS staging, no barrier:
 //     xfrag[(k/32)*64 + ((k/8)%4)*16 + m][k%8]  = x[m][k]     (one such [16][K] matrix per 16 utterances)
-// K = d_model linears use one wave per tile (no cross-wave reduction at all); down_proj (K = d_ff)
-// splits K over the 4 waves of a workgroup and reduces through LDS once.
+// A tile's K range is split over the NWK waves of a workgroup (each streams its share into registers) and the
+// partial sums are reduced through LDS once: 2 waves at K = d_model, 8 at K = d_ff (shorter load queues and MFMA
+// chains per wave beat the single-wave form by ~6 % of the layer).
 //
 // RMSNorm (arch/llama.py:64-77) is folded in: the norm weight is multiplied into W when the streaming
 // copy is built (valle_layer_weights.pn_*), and 1/rms(x[m]) scales the accumulator in the epilogue.
@@ -58,11 +59,11 @@ __global__ __launch_bounds__(64 * NWK) void dec_wave_kernel(DecWArgs a) {
         }
         // ---- 2. per-row sum of squares: partial sums per 16-column tile, left by the producer of x
         // (ssq[m][K/16]); this lane adds tiles fq*STEPS .. +STEPS of its row
-        f32x4 sq[NORM ? STEPS / 4 : 1];
+        f32x4 sq[NORM ? KS / 4 : 1];
         if constexpr (NORM) {
 #pragma unroll
-            for (int i = 0; i < STEPS / 4; ++i)
-                sq[i] = *reinterpret_cast<const f32x4*>(a.ssq_in + (size_t)m * (KS * 4) + fq * STEPS + i * 4);
+            for (int i = 0; i < KS / 4; ++i)
+                sq[i] = *reinterpret_cast<const f32x4*>(a.ssq_in + (size_t)m * (KS * 4) + fq * KS + i * 4);
         }
         // ---- 3. activations first (L2-resident, back quickly), then the weight stream: a wave can have 64
         // vector-memory instructions outstanding, exactly the 32 + 32 of a K = 1024 tile
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(64 * NWK) void dec_wave_kernel(DecWArgs a) {
         if constexpr (NORM) {
             float ss = 0.f;
 #pragma unroll
-            for (int i = 0; i < STEPS / 4; ++i) ss += (sq[i][0] + sq[i][1]) + (sq[i][2] + sq[i][3]);
+            for (int i = 0; i < KS / 4; ++i) ss += (sq[i][0] + sq[i][1]) + (sq[i][2] + sq[i][3]);
             ss += __shfl_xor(ss, 16, 64);
             ss += __shfl_xor(ss, 32, 64);
             scale = 1.0f / sqrtf(ss * (1.0f / (float)K) + a.eps);
@@ -172,6 +173,28 @@ static int dec_wave_launch(const DecWArgs& a, hipStream_t s) {
     return VALLE_OK;
 }
 
+// K-split of one 16-row tile over the waves of a workgroup.  Measured on the decode-layer chain (tools/micro_dec,
+// tools/run_dec_variants.sh, B = 16): 2 waves for K = 1024 and 8 waves for K = 4096 give 30.0 us per layer against
+// 31.8 us for (1, 4); more waves lose again to the LDS reduction.  VALLE_DEC_NWK / VALLE_DEC_NWK_DN override (dev).
+static int dec_variant() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VALLE_DEC_NWK"); v = e ? atoi(e) : 2; }
+    return v;
+}
+static int dec_variant_dn() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VALLE_DEC_NWK_DN"); v = e ? atoi(e) : 8; }
+    return v;
+}
+#define DEC_K1024(EPI, NORM) \
+    switch (dec_variant()) { \
+        case 1: return dec_wave_launch<EPI, 16, 1, NORM>(a, s); \
+        case 2: return dec_wave_launch<EPI, 8, 2, NORM>(a, s); \
+        case 4: return dec_wave_launch<EPI, 4, 4, NORM>(a, s); \
+        case 8: return dec_wave_launch<EPI, 2, 8, NORM>(a, s); \
+        default: return dec_wave_launch<EPI, 1, 16, NORM>(a, s); \
+    }
+
 // K = d_model in {256, 1024} for the norm-prologue linears (QKV, gate/up, head) and o_proj;
 // down_proj K = d_ff in {1024, 4096}.
 int valle_dec_wave_linear(const DecWArgs& a, int epilogue, hipStream_t s) {
@@ -180,15 +203,19 @@ int valle_dec_wave_linear(const DecWArgs& a, int epilogue, hipStream_t s) {
     const int K = a.K;
     if (a.norm) {
         switch (epilogue) {
-            case VALLE_EPI_GEGLU:  if (K == 256) return dec_wave_launch<VALLE_EPI_GEGLU, 4, 1, true>(a, s);  if (K == 1024) return dec_wave_launch<VALLE_EPI_GEGLU, 16, 1, true>(a, s); break;
-            case VALLE_EPI_F32OUT: if (K == 256) return dec_wave_launch<VALLE_EPI_F32OUT, 4, 1, true>(a, s); if (K == 1024) return dec_wave_launch<VALLE_EPI_F32OUT, 16, 1, true>(a, s); break;
-            case DEC_EPI_QKV:      if (K == 256) return dec_wave_launch<DEC_EPI_QKV, 4, 1, true>(a, s);      if (K == 1024) return dec_wave_launch<DEC_EPI_QKV, 16, 1, true>(a, s); break;
+            case VALLE_EPI_GEGLU:  if (K == 256) return dec_wave_launch<VALLE_EPI_GEGLU, 4, 1, true>(a, s);  if (K == 1024) DEC_K1024(VALLE_EPI_GEGLU, true) break;
+            case VALLE_EPI_F32OUT: if (K == 256) return dec_wave_launch<VALLE_EPI_F32OUT, 4, 1, true>(a, s); if (K == 1024) DEC_K1024(VALLE_EPI_F32OUT, true) break;
+            case DEC_EPI_QKV:      if (K == 256) return dec_wave_launch<DEC_EPI_QKV, 4, 1, true>(a, s);      if (K == 1024) DEC_K1024(DEC_EPI_QKV, true) break;
         }
     } else if (epilogue == VALLE_EPI_RESID) {
         VALLE_REQUIRE(a.resid != nullptr, VALLE_E_ARG, "decode linear: residual missing");
         if (K == 256) return dec_wave_launch<VALLE_EPI_RESID, 4, 1, false>(a, s);
-        if (K == 1024) return dec_wave_launch<VALLE_EPI_RESID, 16, 1, false>(a, s);
-        if (K == 4096) return dec_wave_launch<VALLE_EPI_RESID, 16, 4, false>(a, s);
+        if (K == 1024) DEC_K1024(VALLE_EPI_RESID, false)
+        if (K == 4096) switch (dec_variant_dn()) {
+            case 4: return dec_wave_launch<VALLE_EPI_RESID, 16, 4, false>(a, s);
+            case 8: return dec_wave_launch<VALLE_EPI_RESID, 8, 8, false>(a, s);
+            default: return dec_wave_launch<VALLE_EPI_RESID, 4, 16, false>(a, s);
+        }
     }
     valle_set_error("decode linear: combination not built (K=%d norm=%d epilogue=%d)", K, a.norm, epilogue);
     return VALLE_E_UNSUPPORTED;
