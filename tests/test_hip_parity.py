@@ -64,7 +64,7 @@ def test_rmsnorm(gpu_device, dtype):
 
 @pytest.mark.parametrize("dtype,epi", [(torch.float32, 0), (torch.bfloat16, 0), (torch.float32, 1), (torch.bfloat16, 1), (torch.bfloat16, 2), (torch.float32, 2),
                                        (torch.bfloat16, 3), (torch.float32, 3)])
-@pytest.mark.parametrize("shape", [(200, 384, 256), (129, 1025, 1024), (16, 1024, 4096), (300, 1000, 512), (1100, 4160, 512), (2100, 1000, 2048)])
+@pytest.mark.parametrize("shape", [(200, 384, 256), (129, 1025, 1024), (16, 1024, 4096), (300, 1000, 512), (1100, 4160, 512), (2100, 1000, 2048), (2500, 1024, 4096)])
 def test_gemm_epilogues(gpu_device, dtype, epi, shape):
     from vall_e_amd import _lib as L
     M, N, K = shape
