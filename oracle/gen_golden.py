@@ -511,6 +511,45 @@ def scen_tiny_prefix_context():
                     prefix_context=([p.clone() for p in phns1], [f.clone() for f in full1], [int(f.shape[0]) for f in full1]))
 
 
+def scen_tiny_ar_options():
+    """AR call options of ar_nar.py:727-729 (input_prompt_prefix: the prompt's level-0 codes open the response and the
+    prompt segment is empty), :874-883 (refine_on_stop: the last iteration's logits re-read greedily) and
+    prefix_context together with classifier-free guidance (:736-745, :785-800)."""
+    mk = lambda s: synth_batch(s, 2, n_phn=10, n_prom=16, ragged=True)
+    ar_nar_scenario("tiny_prompt_prefix", "tiny", mk, 101, steps=14, ar_kw=dict(input_prompt_prefix=True), nar=False)
+    # utterances must stop at different steps: the shorter one's slice then comes from the END of the last
+    # iteration's logits (ar_nar.py:878), not from its own rows -- the quirk the golden has to carry
+    for seed in range(31, 60):
+        phns, proms, langs = mk(seed)
+        d, gap = _ar_nar_scenario("tiny_refine", "tiny", phns, proms, langs, 40, nar=False, model_kw=dict(stop_bias=0.6),
+                                  ar_kw=dict(length_penalty=-1.0, refine_on_stop=True))
+        lens = [len(d[f"ar_codes_{i}"]) for i in range(2)]
+        if gap > MIN_GAP and lens[0] != lens[1] and min(lens) > 0:
+            d["input_seed"] = np.int64(seed)
+            save("tiny_refine", **d)
+            break
+    else:
+        raise RuntimeError("tiny_refine: no seed with different stop steps")
+    ref = rh.load_reference()
+    model, mcfg = get_ref_model("tiny")
+    phns1, proms, langs = synth_batch(91, 2, n_phn=9, n_prom=14, ragged=True)
+    phns2, _, _ = synth_batch(92, 2, n_phn=11, n_prom=14, ragged=True)
+    codes1 = run_ar(model, phns1, proms, langs, max_duration=10, temperature=0.0)
+    ctx = ([p.clone() for p in phns1], [c.clone() for c in codes1], [int(c.shape[0]) for c in codes1])
+    with Recorder(ref) as rec:
+        codes2 = run_ar(model, phns2, proms, langs, max_duration=9, temperature=0.0, prefix_context=ctx, cfg_strength=2.0)
+    d = input_arrays(phns1, proms, langs)
+    d.update(pack_list("phn2", phns2)), d.update(pack_list("codes1", codes1)), d.update(pack_list("codes2", codes2))
+    d["steps1"], d["steps2"], d["cfg_strength"] = np.int64(10), np.int64(9), np.float64(2.0)
+    d["step_logits2"] = torch.stack([torch.stack(c["logits"]) for c in rec.calls[0::2]])   # conditional pass's last rows (before guidance), every step
+    gaps = np.array([[top2_gap(r) for r in c["logits"]] for c in rec.calls[0::2]])
+    d["min_gap"] = np.float64(gaps.min())
+    print(f"  [tiny_prefix_cfg] min top-2 gap {gaps.min():.3e}, codes2 {[c.tolist() for c in codes2]}")
+    if gaps.min() <= MIN_GAP:
+        raise RuntimeError("tiny_prefix_cfg: margin too small")
+    save("tiny_prefix_cfg", **d)
+
+
 def scen_full_b1():
     ref = rh.load_reference()
     phns, proms, langs = qnt_inputs()
@@ -564,6 +603,7 @@ SCENARIOS = {
     "tiny_len": scen_tiny_len,
     "tiny_prefix_context": scen_tiny_prefix_context,
     "tiny_noncausal": scen_tiny_noncausal,
+    "tiny_ar_options": scen_tiny_ar_options,
     "full_b1": scen_full_b1,
     "full_b3": scen_full_b3,
     "full_narlen": scen_full_narlen,

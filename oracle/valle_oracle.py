@@ -463,8 +463,15 @@ class Oracle:
         temperature = kw.get("temperature", 1.0)
         cfg_strength = kw.get("cfg_strength", 0.0)
         cfg_rescale = kw.pop("cfg_rescale", 0.7)
+        input_prompt_prefix = kw.pop("input_prompt_prefix", False)
+        refine_on_stop = kw.pop("refine_on_stop", False)
         B = len(phns)
         seqs = [torch.zeros(0, dtype=torch.int64) for _ in range(B)]
+        start = [0] * B
+        if input_prompt_prefix:                                              # ar_nar.py:727-729: the prompt's level-0 codes
+            start = [int(p.shape[0]) for p in proms]                         # open the response, the prompt segment is empty
+            seqs = [p[:, 0].long() for p in proms]
+            proms = [torch.zeros(0, dtype=torch.int64) for _ in proms]
         if prefix_context is not None:
             prefix_text, prefix_resps, prefix_lens = prefix_context
             phns = [torch.cat([p[:-1].long(), t[1:].long()]) for p, t in zip(prefix_text, phns)]
@@ -479,7 +486,7 @@ class Oracle:
             if use_cache:
                 logits = self._forward_cached(phns, langs, proms, seqs, kv, first=(n == 0))
             else:
-                logits = self.forward(self._plans(phns, langs, proms, seqs, 0), rows=[len(s) + 1 for s in seqs])
+                logits = self.forward(self._plans(phns, langs, proms, seqs, 0), rows=None if refine_on_stop else [len(s) + 1 for s in seqs])
             if cfg_strength > 0:
                 null = self.forward(self._plans(null_phn, langs, None, seqs, 0), rows=[len(s) + 1 for s in seqs])
                 logits = cfg_combine(logits, null, cfg_strength, [len(s) + 1 for s in seqs], cfg_rescale)
@@ -497,6 +504,10 @@ class Oracle:
         for i, s in enumerate(seqs):
             hit = (s == self.stop_token).nonzero()
             s = s if len(hit) == 0 else s[: int(hit.min())]
+            s = s[start[i]:]                                                  # ar_nar.py:872
+            if refine_on_stop:                                               # ar_nar.py:874-883: greedy re-read of the LAST
+                n = int(s.shape[0])                                          # iteration's logits, rows counted from its end
+                s = logits[i][-n - 1:-1].argmax(dim=-1)
             out.append(s[int(prefix_context[2][i]):] if prefix_context is not None else s)
         return (out, last_logits) if return_logits else out
 

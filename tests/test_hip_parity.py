@@ -405,6 +405,28 @@ def test_tiny_prefix_context_and_tts_inference(gpu_device):
         assert lines[1].shape[1] == 8
 
 
+def test_tiny_ar_options(gpu_device):
+    """input_prompt_prefix (ar_nar.py:727-729) and refine_on_stop (ar_nar.py:874-883, utterances stopping at different
+    steps; step_chunk=5 makes the decode loop overrun the reference's last iteration, which the refine pass undoes)."""
+    _ar_nar("tiny", "tiny_prompt_prefix")
+    _ar_nar("tiny", "tiny_refine", stop_bias=0.6)
+
+
+def test_tiny_prefix_context_with_cfg(gpu_device):
+    """Rolling context + AR classifier-free guidance: codes identical to the reference's."""
+    z = load_golden("tiny_prefix_cfg")
+    phns1, proms, langs = golden_inputs(z)
+    B = len(phns1)
+    phns2 = [torch.from_numpy(z[f"phn2_{i}"]) for i in range(B)]
+    codes1 = [torch.from_numpy(z[f"codes1_{i}"].astype(np.int64)) for i in range(B)]
+    m = hip_model("tiny")
+    ctx = (phns1, codes1, [int(c.shape[0]) for c in codes1])
+    codes2 = m(task_list=["tts"] * B, phns_list=phns2, proms_list=proms, lang_list=langs, max_duration=int(z["steps2"]),
+               temperature=0.0, prefix_context=ctx, cfg_strength=float(z["cfg_strength"]))
+    for b in range(B):
+        np.testing.assert_array_equal(codes2[b].cpu().numpy(), z[f"codes2_{b}"])
+
+
 def test_edge_shapes_match_oracle(gpu_device):
     """Smallest and most ragged shapes: no prompt, one-phoneme text, one AR step, one-frame NAR, batch of one."""
     m, o = hip_model("tiny"), oracle("tiny")

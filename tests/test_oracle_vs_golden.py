@@ -250,6 +250,32 @@ def test_tiny_prefix_context_narlen():
         np.testing.assert_array_equal(out[b].numpy(), z[f"codes_{b}"])
 
 
+def test_tiny_ar_options():
+    """input_prompt_prefix (ar_nar.py:727-729) and refine_on_stop (ar_nar.py:874-883; the two utterances stop at
+    different steps, so the shorter one's rows come from the end of the last iteration's logits)."""
+    _ar_nar("tiny", "tiny_prompt_prefix")
+    z = load_golden("tiny_refine")
+    assert len(z["ar_codes_0"]) != len(z["ar_codes_1"])
+    _ar_nar("tiny", "tiny_refine", stop_bias=0.6)
+
+
+def test_tiny_prefix_context_with_cfg():
+    """Rolling context together with classifier-free guidance in the AR loop: the null pass carries the prefix codes
+    too (ar_nar.py:786-799) and the guidance statistics run over prefix + generated rows (:800)."""
+    z = load_golden("tiny_prefix_cfg")
+    phns1, proms, langs = golden_inputs(z)
+    B = len(phns1)
+    phns2 = [torch.from_numpy(z[f"phn2_{i}"]) for i in range(B)]
+    codes1 = [torch.from_numpy(z[f"codes1_{i}"].astype(np.int64)) for i in range(B)]
+    o = make_oracle("tiny")
+    ctx = (phns1, codes1, [int(c.shape[0]) for c in codes1])
+    codes2 = o.ar(phns2, proms, langs, max_duration=int(z["steps2"]), temperature=0.0, prefix_context=ctx,
+                  cfg_strength=float(z["cfg_strength"]))
+    assert float(z["min_gap"]) > 1e-3
+    for b in range(B):
+        np.testing.assert_array_equal(codes2[b].numpy(), z[f"codes2_{b}"])
+
+
 def test_full_b1_configs0():
     """BASELINE.json configs[0]: repo-default model, data/qnt.enc prompt, greedy AR + NAR."""
     _ar_nar("full", "full_b1")

@@ -132,13 +132,22 @@ class AR_NAR(Base):
         return_logits = kw.pop("return_logits", False)
         prof = kw.pop("profile", None)      # list: receives (start_event, end_event, n_steps, ctx_len_host) per decode chunk
         prefix_context = kw.get("prefix_context", None)
+        input_prompt_prefix = kw.pop("input_prompt_prefix", False)
+        refine_on_stop = kw.pop("refine_on_stop", False)
         sp = self.sample_params(**kw)
         B = len(phns_list)
         dev = self.device
         n_steps = max_duration // max(1, self.causal_size)
+        if refine_on_stop and cfg_strength > 0:
+            raise NotImplementedError("refine_on_stop together with AR classifier-free guidance")
 
         prefix = [np.zeros(0, np.int64) for _ in range(B)]
         prefix_lens = [0] * B
+        start_slice = [0] * B
+        if input_prompt_prefix:                                               # ar_nar.py:727-729: the prompt's level-0 codes
+            start_slice = [int(_np(p).shape[0]) for p in proms_list]          # open the response; the prompt segment is empty
+            prefix = [_np(p)[:, 0] for p in proms_list]
+            proms_list = [torch.zeros(0, dtype=torch.int16) for _ in range(B)]
         if prefix_context is not None:                                        # ar_nar.py:736-742
             prefix_text, prefix_resps, prefix_lens = prefix_context
             phns_list = [torch.cat([torch.as_tensor(p)[:-1], torch.as_tensor(t)[1:]]) for p, t in zip(prefix_text, phns_list)]
@@ -169,7 +178,9 @@ class AR_NAR(Base):
             stride = B * H * cache_T * Dh
             kc = torch.empty((Lyr, B, H, cache_T, Dh), dtype=self.dtype, device=dev)
             vc = torch.empty_like(kc)
-            rows, off = self.tail_rows(plan, [1] * B)
+            # guidance needs the logits of every response row so far (samplers.py:178-189): with a prefix those are
+            # the prefill's last len(prefix) + 1 rows
+            rows, off = self.tail_rows(plan, [len(p) + 1 for p in prefix] if cfg_strength > 0 else [1] * B)
             pos0 = torch.zeros(B, dtype=torch.int32, device=dev)
             lg = self.forward_dense(plan, rows, cache=(kc, vc, cache_T, stride, slot, pos0))
             ctx_len = self._i32(plan.lens)
@@ -211,24 +222,29 @@ class AR_NAR(Base):
             # classifier-free guidance: positive and null caches advance together; the combine
             # needs every response row's logits (std over rows x vocab, samplers.py:187-188), which
             # under causality are the last-row logits of the earlier steps -> keep a history
-            hist = [torch.empty((B, n_steps + 1, ld), dtype=torch.float32, device=dev) for _ in range(2)]
-            n_prefix = [len(p) for p in prefix]
-            if any(n_prefix):
-                raise NotImplementedError("prefix_context together with AR classifier-free guidance")
+            # utterance b's rows sit right-aligned at hist[k][b, maxp - len(prefix[b]) : maxp + step + 1]
+            n_prefix = np.array([len(p) for p in prefix], dtype=np.int64)
+            maxp = int(n_prefix.max())
+            hcap = maxp + n_steps + 1
+            hist = [torch.zeros((B, hcap, ld), dtype=torch.float32, device=dev) for _ in range(2)]
+            foff = np.concatenate(([0], np.cumsum(n_prefix + 1)))
             for step in range(n_steps):
                 for k in range(2):
                     if step == 0:
-                        hist[k][:, 0] = first_logits[k]
+                        for b in range(B):
+                            hist[k][b, maxp - n_prefix[b]: maxp + 1] = first_logits[k][foff[b]:foff[b + 1]]
                     else:
                         lg = torch.empty((B, ld), dtype=torch.float32, device=dev)
                         L.check(lib.valle_ar_decode(self._handle, C.byref(states[k][0]), None, 1, L.ptr(lg), ld,
                                                     L.ptr(ws), ws.numel(), stream))
-                        hist[k][:, step] = lg
-                n_rows = step + 1
-                posl = hist[0][:, :n_rows].reshape(B * n_rows, ld).contiguous()
-                negl = hist[1][:, :n_rows].reshape(B * n_rows, ld).contiguous()
-                self.cfg_combine(posl, negl, V, np.arange(B + 1, dtype=np.int32) * n_rows, cfg_strength, cfg_rescale)
-                last = posl.view(B, n_rows, ld)[:, -1].contiguous()
+                        hist[k][:, maxp + step] = lg
+                n_rows = n_prefix + step + 1
+                roff = np.concatenate(([0], np.cumsum(n_rows))).astype(np.int32)
+                sel = torch.from_numpy(np.concatenate([b * hcap + np.arange(maxp - n_prefix[b], maxp + step + 1) for b in range(B)])).to(dev)
+                posl = hist[0].view(B * hcap, ld).index_select(0, sel)
+                negl = hist[1].view(B * hcap, ld).index_select(0, sel)
+                self.cfg_combine(posl, negl, V, roff, cfg_strength, cfg_rescale)
+                last = posl.index_select(0, torch.from_numpy(roff[1:].astype(np.int64) - 1).to(dev)).contiguous()
                 if return_logits:
                     all_logits.append(last[:, :V].clone())
                 self._ar_sample_append(last, V, seq, seq_len, [states[0][1][2], states[1][1][2]], stopped, scores, sp, cap,
@@ -243,11 +259,43 @@ class AR_NAR(Base):
             hit = np.nonzero(r == self.stop_token)[0]                         # _prune, base.py:290-299
             if len(hit):
                 r = r[: hit.min()]
-            r = r[prefix_lens[i] if prefix_context is not None else 0:]       # ar_nar.py:886-888
-            out.append(torch.from_numpy(r).to(dev))
+            out.append(r[start_slice[i]:])                                    # ar_nar.py:872
+        if refine_on_stop:
+            out = self._refine_on_stop(out, seq_h, len_h, [len(p) for p in prefix], n_steps, phns_list, lang_list, proms_list)
+        if prefix_context is not None:                                        # ar_nar.py:886-888
+            out = [r[prefix_lens[i]:] for i, r in enumerate(out)]
+        out = [torch.from_numpy(np.ascontiguousarray(r)).to(dev) for r in out]
         if return_logits:
             return out, all_logits
         return out
+
+    def _refine_on_stop(self, out, seq_h, len_h, n_prefix, n_steps, phns_list, lang_list, proms_list):
+        """ar_nar.py:874-883: the reference re-reads the logits of its LAST iteration greedily -- for every utterance
+        the ``len(result)`` rows that end one before the last row, counted from the end of that iteration's sequence
+        (for an utterance that stopped earlier than the others these are not its own first rows; kept).  The last
+        iteration is the one in which the last utterance stopped (the decode loop here checks ``stopped`` once per
+        chunk and may have run further); its input is recomputed in one dense pass."""
+        B = len(out)
+        gen = [seq_h[i, n_prefix[i]: len_h[i]] for i in range(B)]
+        first_stop = [np.nonzero(g == self.stop_token)[0] for g in gen]
+        n_iter = max(int(h[0]) + 1 for h in first_stop) if all(len(h) for h in first_stop) else n_steps
+        resp_in = [seq_h[i, : n_prefix[i] + n_iter - 1].astype(np.int64) for i in range(B)]
+        plan = self.plan(phns_list, lang_list, proms_list, resp_in, 0)
+        rows, off = [], [0]
+        for i in range(B):
+            T, n = int(plan.lens[i]), len(out[i])
+            lo, hi = max(T - n - 1, 0), T - 1                                 # python slice [-n-1:-1] of T rows
+            rows.append(int(plan.cu[i]) + np.arange(lo, hi, dtype=np.int32))
+            off.append(off[-1] + hi - lo)
+        rows = np.concatenate(rows) if off[-1] else np.zeros(0, np.int32)
+        if off[-1] == 0:
+            return [np.zeros(0, np.int64) for _ in range(B)]
+        logits = self.forward_dense(plan, rows)
+        off = np.array(off, dtype=np.int32)
+        ids, _ = self.sample_rows(logits, self.cls_tokens[0], off, None, nar_mode=1,
+                                  params=self.sample_params(temperature=0.0, top_no=0.0))
+        ids = ids.cpu().numpy().astype(np.int64)
+        return [ids[off[i]:off[i + 1]] for i in range(B)]
 
     def _ar_sample_append(self, logits, V, seq, seq_len, ctx_lens, stopped, scores, sp, cap, step, bump_ctx=False):
         """Sampling of one AR row per utterance from explicit logits + token append (host-driven

@@ -21,7 +21,7 @@ Logits = namedtuple("Logits", ["logits", "state", "inputs", "loss", "attentions"
 Sampled = namedtuple("Sampled", ["ids", "logits", "scores", "entropy"])                             # base.py:47
 
 UNSUPPORTED_SAMPLERS = ("beam_width", "mirostat_tau", "mirostat_eta", "entropix_sampling",
-                        "refine_on_stop", "input_prompt_prefix", "prefix_silence", "layer_skip")
+                        "prefix_silence", "layer_skip")
 
 
 def _round_up(a, b):
