@@ -530,8 +530,14 @@ def scen_tiny_ar_options():
             break
     else:
         raise RuntimeError("tiny_refine: no seed with different stop steps")
+    # mirostat_tau / mirostat_eta: forward_ar builds its state list (ar_nar.py:702-704) but never hands it to
+    # Base.sample (the call at :804-808 passes no ``mirostat=``), so the options change nothing -- pinned here
+    ar_nar_scenario("tiny_mirostat_tau", "tiny", mk, 101, steps=10, ar_kw=dict(mirostat_tau=3.0, mirostat_eta=0.1), nar=False)
     ref = rh.load_reference()
     model, mcfg = get_ref_model("tiny")
+    z = np.load(GOLD / "tiny_mirostat_tau.npz")
+    plain = run_ar(model, *mk(int(z["input_seed"])), max_duration=10, temperature=0.0)
+    assert all(np.array_equal(p.numpy(), z[f"ar_codes_{i}"]) for i, p in enumerate(plain)), "mirostat_tau changed the codes"
     phns1, proms, langs = synth_batch(91, 2, n_phn=9, n_prom=14, ragged=True)
     phns2, _, _ = synth_batch(92, 2, n_phn=11, n_prom=14, ragged=True)
     codes1 = run_ar(model, phns1, proms, langs, max_duration=10, temperature=0.0)

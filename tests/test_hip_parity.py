@@ -409,6 +409,7 @@ def test_tiny_ar_options(gpu_device):
     """input_prompt_prefix (ar_nar.py:727-729) and refine_on_stop (ar_nar.py:874-883, utterances stopping at different
     steps; step_chunk=5 makes the decode loop overrun the reference's last iteration, which the refine pass undoes)."""
     _ar_nar("tiny", "tiny_prompt_prefix")
+    _ar_nar("tiny", "tiny_mirostat_tau")             # accepted, no effect: as in the reference (ar_nar.py:702-704, :804-808)
     _ar_nar("tiny", "tiny_refine", stop_bias=0.6)
 
 

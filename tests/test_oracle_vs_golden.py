@@ -254,6 +254,7 @@ def test_tiny_ar_options():
     """input_prompt_prefix (ar_nar.py:727-729) and refine_on_stop (ar_nar.py:874-883; the two utterances stop at
     different steps, so the shorter one's rows come from the end of the last iteration's logits)."""
     _ar_nar("tiny", "tiny_prompt_prefix")
+    _ar_nar("tiny", "tiny_mirostat_tau")             # the options are a no-op in the reference's AR loop
     z = load_golden("tiny_refine")
     assert len(z["ar_codes_0"]) != len(z["ar_codes_1"])
     _ar_nar("tiny", "tiny_refine", stop_bias=0.6)

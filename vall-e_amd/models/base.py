@@ -20,8 +20,10 @@ from ..weights import classifier_layout, state_dict_spec
 Logits = namedtuple("Logits", ["logits", "state", "inputs", "loss", "attentions", "hidden_states"])  # base.py:46
 Sampled = namedtuple("Sampled", ["ids", "logits", "scores", "entropy"])                             # base.py:47
 
-UNSUPPORTED_SAMPLERS = ("beam_width", "mirostat_tau", "mirostat_eta", "entropix_sampling",
-                        "prefix_silence", "layer_skip")
+# mirostat_tau / mirostat_eta are accepted and change nothing, as in the reference: forward_ar builds the mirostat
+# state list (ar_nar.py:702-704) but its Base.sample call (:804-808) never passes ``mirostat=``, so basic sampling
+# runs (golden tiny_mirostat_tau).  Only a caller-made ``mirostat=[state, ...]`` kwarg reaches samplers.py:197-238.
+UNSUPPORTED_SAMPLERS = ("beam_width", "entropix_sampling", "prefix_silence", "layer_skip")
 
 
 def _round_up(a, b):
