@@ -451,6 +451,22 @@ def narlen_scenario(name, kind, phns, proms, langs, lens, max_steps, **kw):
 def scen_tiny_narlen():
     phns, proms, langs = synth_batch(51, 2, n_phn=10, n_prom=16, ragged=True)
     narlen_scenario("tiny_narlen", "tiny", phns, proms, langs, lens=[18, 25], max_steps=6)
+    # sampling_scores_masked_only (ar_nar.py:459-460): positions that were not masked in a step score 1.0
+    # -- inputs searched so that the option changes the codes (a kept position re-scores below the cut otherwise)
+    model, _ = get_ref_model("tiny")
+    for seed in range(52, 90):
+        phns, proms, langs = synth_batch(seed, 2, n_phn=10, n_prom=16, ragged=True)
+        a = run_narlen(model, phns, proms, langs, [18, 25], max_steps=8, temperature=0.0, max_levels=1)
+        b = run_narlen(model, phns, proms, langs, [18, 25], max_steps=8, temperature=0.0, max_levels=1, sampling_scores_masked_only=True)
+        if any(not torch.equal(x, y) for x, y in zip(a, b)):
+            try:
+                narlen_scenario("tiny_narlen_masked_only", "tiny", phns, proms, langs, lens=[18, 25], max_steps=8,
+                                sampling_scores_masked_only=True)
+            except RuntimeError:
+                continue
+            break
+    else:
+        raise RuntimeError("tiny_narlen_masked_only: no inputs where the option matters")
 
 
 def scen_tiny_len():

@@ -566,6 +566,7 @@ class Oracle:
         start, end = kw.get("denoise_start", 0.0), kw.get("denoise_end", 1.0)
         max_steps = math.floor(max_steps * (end - start))
         remask = kw.get("sampling_scores_remask", False)
+        masked_only = kw.pop("sampling_scores_masked_only", False)
         lens = [clamp(int(l), min_len, max_len) for l in lens]
         B = len(lens)
         prefix = [torch.zeros(0, dtype=torch.int64) for _ in range(B)]
@@ -597,6 +598,8 @@ class Oracle:
                               temperature=0.0, **kw)
             resps = [torch.where(m, i, r) for m, i, r in zip(is_masked, ids, resps)]
             scores = [s.float() for s in sc]
+            if masked_only:                                              # ar_nar.py:459-460: kept tokens score 1.0
+                scores = [torch.where(m, s, torch.ones_like(s)) for m, s in zip(is_masked, scores)]
         return resps
 
     def nar_len(self, phns, proms, langs, lens, **kw):

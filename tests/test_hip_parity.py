@@ -302,19 +302,20 @@ def test_full_b3_ragged_codes_identical(gpu_device):
     _ar_nar("full", "full_b3")
 
 
-def _narlen(kind, name):
+def _narlen(kind, name, **kw):
     z = load_golden(name)
     phns, proms, langs = golden_inputs(z)
     m = hip_model(kind)
     B = len(phns)
     full = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs,
-             len_list=[int(x) for x in z["lens"]], max_steps=int(z["max_steps"]), temperature=0.0)
+             len_list=[int(x) for x in z["lens"]], max_steps=int(z["max_steps"]), temperature=0.0, **kw)
     for b in range(B):
         np.testing.assert_array_equal(full[b].cpu().numpy(), z[f"codes_{b}"])
 
 
 def test_tiny_narlen_codes_identical(gpu_device):
     _narlen("tiny", "tiny_narlen")
+    _narlen("tiny", "tiny_narlen_masked_only", sampling_scores_masked_only=True)      # ar_nar.py:459-460
 
 
 def test_full_narlen_codes_identical(gpu_device):

@@ -168,7 +168,7 @@ def test_tiny_cfg():
     _ar_nar("tiny", "tiny_cfg")
 
 
-def _narlen(kind, name):
+def _narlen(kind, name, **kw):
     z = load_golden(name)
     phns, proms, langs = golden_inputs(z)
     o = make_oracle(kind)
@@ -177,13 +177,18 @@ def _narlen(kind, name):
         plans = [vo.plan_sequence(phns[i], langs[i], proms[i], torch.full((int(z["lens"][i]),), o.mask_token), 0, timestep=True)
                  for i in range(len(phns))]
         assert_close(o.forward(plans, rows=[int(x) for x in z["lens"]])[0], z["level0_first_step_logits_0"][-n0:], 5e-4, 5e-4)
-    full = o.nar_len(phns, proms, langs, [int(x) for x in z["lens"]], max_steps=int(z["max_steps"]), temperature=0.0)
+    full = o.nar_len(phns, proms, langs, [int(x) for x in z["lens"]], max_steps=int(z["max_steps"]), temperature=0.0, **kw)
     for b in range(len(phns)):
         np.testing.assert_array_equal(full[b].numpy(), z[f"codes_{b}"])
 
 
 def test_tiny_narlen():
     _narlen("tiny", "tiny_narlen")
+    _narlen("tiny", "tiny_narlen_masked_only", sampling_scores_masked_only=True)      # ar_nar.py:459-460
+    z = load_golden("tiny_narlen_masked_only")                 # inputs were searched so that the option matters
+    phns, proms, langs = golden_inputs(z)
+    plain = make_oracle("tiny").nar_len(phns, proms, langs, [int(x) for x in z["lens"]], max_steps=int(z["max_steps"]), temperature=0.0)
+    assert any((plain[i].numpy() != z[f"codes_{i}"]).any() for i in range(2))
 
 
 @pytest.mark.parametrize("name", ["tiny_len", "tiny_len_stop"])

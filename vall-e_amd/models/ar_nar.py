@@ -264,7 +264,10 @@ class AR_NAR(Base):
             out = self._refine_on_stop(out, seq_h, len_h, [len(p) for p in prefix], n_steps, phns_list, lang_list, proms_list)
         if prefix_context is not None:                                        # ar_nar.py:886-888
             out = [r[prefix_lens[i]:] for i, r in enumerate(out)]
-        out = [torch.from_numpy(np.ascontiguousarray(r)).to(dev) for r in out]
+        # one host->device copy for the whole batch (a copy per utterance costs ~50 us of idle GPU each)
+        cuts = np.cumsum([0] + [len(r) for r in out])
+        flat = torch.from_numpy(np.ascontiguousarray(np.concatenate(out)) if cuts[-1] else np.zeros(0, np.int64)).to(dev)
+        out = [flat[cuts[i]:cuts[i + 1]] for i in range(B)]
         if return_logits:
             return out, all_logits
         return out
@@ -413,9 +416,9 @@ class AR_NAR(Base):
         max_steps = math.floor(max_steps * (end_noise - start_noise))
         remasking = kw.get("sampling_scores_remask", False)
         prefix_context = kw.pop("prefix_context", None)
-        for k in ("sampling_scores_masked_only", "vc_list"):
-            if kw.get(k):
-                raise NotImplementedError(f"{k} is not built on the HIP path")
+        masked_only = kw.pop("sampling_scores_masked_only", False)
+        if kw.get("vc_list") is not None:
+            raise NotImplementedError("vc_list is not built on the HIP path")
         if start_noise > 0.0:
             raise NotImplementedError("denoising from an existing sequence (denoise_start > 0)")
         if quant_levels is not None and any(q != 0 for q in quant_levels):
@@ -475,6 +478,6 @@ class AR_NAR(Base):
             sp2 = self.sample_params(temperature=0.0, rep_pen_passes=2 if kw.get("repetition_penalty", 1.0) != 1.0 else 1, **kw)
             _, sc = self.sample_rows(logits, V, roff, None, nar_mode=1, params=sp2, dev=sdev)
             codes = torch.where(is_masked.bool(), ids, codes)                  # ar_nar.py:457
-            scores = sc                                                        # ar_nar.py:462
+            scores = torch.where(is_masked.bool(), sc, torch.ones_like(sc)) if masked_only else sc   # ar_nar.py:459-462
         codes = codes.to(torch.int16)
         return [codes[off[i]:off[i + 1]] for i in range(B)]
