@@ -572,6 +572,41 @@ def scen_tiny_ar_options():
     save("tiny_prefix_cfg", **d)
 
 
+def scen_tiny_task_prompt():
+    """Task tokens inside the prompt ([task, codes], what inference.py:489-493 builds for ns / sr): a tasks_emb row in
+    front of the prompt codes (base.py:780-782, :850-856) that the position ids do not count (base.py:964-974, :988-990)."""
+    ref = rh.load_reference()
+    model, mcfg = get_ref_model("tiny")
+    for seed in range(111, 130):
+        phns, proms, langs = synth_batch(seed, 2, n_phn=10, n_prom=16, ragged=True)
+        tasks = ["ns", "sr"]
+        mk = lambda: [[t, p.clone()] for t, p in zip(tasks, proms)]
+        with Recorder(ref) as rec, torch.inference_mode():
+            codes = model(task_list=["tts"] * 2, phns_list=[p.clone() for p in phns], proms_list=mk(), lang_list=[l.clone() for l in langs],
+                          disable_tqdm=True, max_duration=10, temperature=0.0)
+            n_ar = len(rec.calls)
+            full = model(task_list=["tts"] * 2, phns_list=[p.clone() for p in phns], proms_list=mk(), lang_list=[l.clone() for l in langs],
+                         resps_list=[c.clone() for c in codes], disable_tqdm=True, temperature=0.0)
+            inputs = model.inputs(task_list=["tts"] * 2, phns_list=phns, proms_list=mk(), resps_list=[c.clone() for c in codes],
+                                  lang_list=langs, quant_levels=[0, 0])
+            x = model.inputs_to_embeddings(inputs, [0, 0])
+            m = torch.ones((1, x[0].shape[0]))
+            pos0 = model.inputs_to_position_ids(inputs[:1], m)[0]
+        gap = min(top2_gap(r) for c in rec.calls[:n_ar] for r in c["logits"])
+        print(f"  [tiny_task_prompt] seed {seed} AR min top-2 gap {gap:.3e}")
+        if gap > MIN_GAP:
+            break
+    else:
+        raise RuntimeError("tiny_task_prompt: no seed with a usable margin")
+    d = input_arrays(phns, proms, langs)
+    d["prompt_tasks"] = np.array(tasks)
+    d.update(pack_list("ar_codes", codes)), d.update(pack_list("nar_codes", full))
+    d["first_logits"] = torch.stack(rec.calls[0]["logits"])
+    d["pos_ids_0"] = pos0
+    d["steps"], d["min_gap"] = np.int64(10), np.float64(gap)
+    save("tiny_task_prompt", **d)
+
+
 def scen_full_b1():
     ref = rh.load_reference()
     phns, proms, langs = qnt_inputs()
@@ -626,6 +661,7 @@ SCENARIOS = {
     "tiny_prefix_context": scen_tiny_prefix_context,
     "tiny_noncausal": scen_tiny_noncausal,
     "tiny_ar_options": scen_tiny_ar_options,
+    "tiny_task_prompt": scen_tiny_task_prompt,
     "full_b1": scen_full_b1,
     "full_b3": scen_full_b3,
     "full_narlen": scen_full_narlen,

@@ -49,6 +49,26 @@ class Plan:
     out_len: int         # length of the output segment
 
 
+# data.py:670-688 (get_task_symmap): rows of tasks_emb
+TASK_SYMMAP = {"tts": 0, "tts-c": 1, "ns": 2, "sr": 3, "tse": 4, "soe": 5, "mask": 6, "eoe": 7, "stt": 8,
+               "len": 0, "nse": 6, "cse": 6, "phn": 0, "un-phn": 0}
+
+
+def _seg_rows(ids):
+    """Embedding rows of a segment; a prompt may be a list of code tensors and task-token strings (base.py:850-856)."""
+    if isinstance(ids, list):
+        return sum(1 if isinstance(p, str) else int(p.shape[0]) for p in ids)
+    return int(ids.shape[0])
+
+
+def _seg_tokens(ids):
+    """What the reference's position ids count (base.py:964-974): in a list prompt only the tensors, so every
+    task token leaves the position list one short and the tail is filled with 1 (base.py:988-990)."""
+    if isinstance(ids, list):
+        return sum(int(p.shape[0]) for p in ids if not isinstance(p, str))
+    return int(ids.shape[0])
+
+
 def plan_sequence(phn, lang, prom, resp, quant_level, *, timestep=False, task="tts", unified_pos=False, len_ids=None):
     """Ordered segments of one utterance + per-segment position ids.
 
@@ -66,7 +86,10 @@ def plan_sequence(phn, lang, prom, resp, quant_level, *, timestep=False, task="t
     segs.append(Segment("quant_level", torch.tensor([quant_level])))
     head = "AR:0:0" if quant_level == 0 else f"NAR:{quant_level-1}:{quant_level}"
     if prom is not None:
-        segs.append(Segment("prom", prom.long()))
+        if isinstance(prom, (list, tuple)):                               # [task token, codes] (inference.py:489-493)
+            segs.append(Segment("prom", [p if isinstance(p, str) else p.long() for p in prom if p is not None]))
+        else:
+            segs.append(Segment("prom", prom.long()))
     if timestep:
         head = "NAR:0:0"
     if task == "len":
@@ -78,16 +101,17 @@ def plan_sequence(phn, lang, prom, resp, quant_level, *, timestep=False, task="t
     out_kind = "len" if task == "len" else "resp"                      # task_outputs, base.py:67-73
     pos = []
     for s in segs:
-        n = s.ids.shape[0]
-        pos.append(torch.arange(n + (0 if s.kind == out_kind else 1)))
+        pos.append(torch.arange(_seg_tokens(s.ids) + (0 if s.kind == out_kind else 1)))
     pos = torch.cat(pos)
-    T = sum(s.ids.shape[0] for s in segs) + len(segs) - 1
+    T = sum(_seg_rows(s.ids) for s in segs) + len(segs) - 1
     if segs[-1].kind != out_kind:   # no output segment: the trailing +1 has no sep row behind it
         pos = pos[:T]
+    if pos.shape[0] < T:            # task tokens are rows the position list did not count: tail filled with 1
+        pos = torch.cat([pos, torch.ones(T - pos.shape[0], dtype=pos.dtype)])
     if unified_pos:
         pos = torch.arange(T)
     assert pos.shape[0] == T, (pos.shape, T)
-    return Plan(segs, head, quant_level, pos, segs[-1].ids.shape[0] if segs[-1].kind == out_kind else 0)
+    return Plan(segs, head, quant_level, pos, _seg_rows(segs[-1].ids) if segs[-1].kind == out_kind else 0)
 
 
 # ------------------------------------------------------------------------- samplers
@@ -302,6 +326,14 @@ class Oracle:
             return self.w["rvq_l_emb.weight"][ids]
         if seg.kind == "len":
             return self.w["len_emb.weight"][ids]
+        if seg.kind == "prom" and isinstance(ids, list):                             # base.py:780-794, :850-856
+            parts = []
+            for p in ids:
+                if isinstance(p, str):
+                    parts.append(self.w["tasks_emb.weight"][torch.tensor([TASK_SYMMAP[p]])])
+                else:
+                    parts.append(self.embed_segment(Segment("prom", p), plan).reshape(-1, self.d))
+            return torch.cat(parts, dim=0)
         if seg.kind == "prom":
             if ids.dim() == 1:
                 return self.w["proms_emb.embeddings.0.weight"][ids]

@@ -429,6 +429,29 @@ def test_tiny_prefix_context_with_cfg(gpu_device):
         np.testing.assert_array_equal(codes2[b].cpu().numpy(), z[f"codes2_{b}"])
 
 
+def test_tiny_task_token_prompt(gpu_device):
+    """[task, codes] prompts (inference.py:489-493; base.py:780-782, :964-990): AR + NAR codes == the reference's."""
+    z = load_golden("tiny_task_prompt")
+    phns, proms, langs = golden_inputs(z)
+    B = len(phns)
+    proms = [[str(t), p] for t, p in zip(z["prompt_tasks"], proms)]
+    m = hip_model("tiny")
+    codes, logits = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=int(z["steps"]),
+                      temperature=0.0, return_logits=True)
+    torch.testing.assert_close(logits[0].cpu(), torch.from_numpy(z["first_logits"]), rtol=1e-3, atol=1e-3)
+    for b in range(B):
+        np.testing.assert_array_equal(codes[b].cpu().numpy(), z[f"ar_codes_{b}"])
+    full = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, resps_list=[c.clone() for c in codes],
+             temperature=0.0)
+    for b in range(B):
+        np.testing.assert_array_equal(full[b].cpu().numpy(), z[f"nar_codes_{b}"])
+    from vall_e_amd.inference import TTS                 # the caller that builds such prompts (inference.py:489-493)
+    tts = TTS(config=model_cfg("tiny"), device="cuda:0", dtype=torch.float32, state_dict=synth_weights("tiny"))
+    for b in range(B):
+        lines = tts.inference([phns[b]], proms[b][1], language=langs[b], task=proms[b][0], temperature=0.0, max_duration=int(z["steps"]))
+        np.testing.assert_array_equal(lines[0].cpu().numpy(), z[f"nar_codes_{b}"])
+
+
 def test_edge_shapes_match_oracle(gpu_device):
     """Smallest and most ragged shapes: no prompt, one-phoneme text, one AR step, one-frame NAR, batch of one."""
     m, o = hip_model("tiny"), oracle("tiny")

@@ -282,6 +282,26 @@ def test_tiny_prefix_context_with_cfg():
         np.testing.assert_array_equal(codes2[b].numpy(), z[f"codes2_{b}"])
 
 
+def test_tiny_task_token_prompt():
+    """[task, codes] prompts (inference.py:489-493): a tasks_emb row the position ids do not count (base.py:964-990)."""
+    z = load_golden("tiny_task_prompt")
+    phns, proms, langs = golden_inputs(z)
+    B = len(phns)
+    proms = [[str(t), p] for t, p in zip(z["prompt_tasks"], proms)]
+    o = make_oracle("tiny")
+    codes0 = [torch.from_numpy(z[f"ar_codes_{b}"].astype(np.int64)) for b in range(B)]
+    plan = vo.plan_sequence(phns[0], langs[0], proms[0], codes0[0], 0)
+    np.testing.assert_array_equal(plan.pos.numpy(), z["pos_ids_0"])
+    assert plan.pos[-1] == 1 and plan.pos[-2] == len(codes0[0]) - 1          # the tail the reference pads with 1
+    codes, logits = o.ar(phns, proms, langs, max_duration=int(z["steps"]), temperature=0.0, return_logits=True)
+    assert_close(logits[0], z["first_logits"], 5e-4, 5e-4)
+    for b in range(B):
+        np.testing.assert_array_equal(codes[b].numpy(), z[f"ar_codes_{b}"])
+    full = o.nar(phns, proms, langs, codes, temperature=0.0)
+    for b in range(B):
+        np.testing.assert_array_equal(full[b].numpy(), z[f"nar_codes_{b}"])
+
+
 def test_full_b1_configs0():
     """BASELINE.json configs[0]: repo-default model, data/qnt.enc prompt, greedy AR + NAR."""
     _ar_nar("full", "full_b1")

@@ -154,14 +154,14 @@ class TTS:
     @torch.inference_mode()
     def inference(self, text, references, language="auto", text_language=None, task="tts", out_path=None, play=False,
                   **sampling_kwargs):
-        """inference.py:361-597, the serial line-by-line path, for ``task="tts"``: every line (a list of phoneme strings
+        """inference.py:361-597, the serial line-by-line path, for tasks ``tts``, ``ns`` and ``sr``: every line (a list of phoneme strings
         / id tensors, or one string split at newlines -- sentence splitting and language detection belong to the text
         front end) runs AR then NAR, or len -> NAR-len; with ``context_history`` = n > 0 the AR call of a line gets the
         previous n lines' phonemes and codes as ``prefix_context`` (:575-584).  Returns the list of per-line (R, 8)
         code tensors the reference hands to ``qnt.decode_to_file`` one after the other (:587).  ``max_duration`` may be
         a list (one value per line)."""
-        if task != "tts":
-            raise NotImplementedError(f"task {task!r}: TTS.inference is built for 'tts'")
+        if task not in ("tts", "ns", "sr"):
+            raise NotImplementedError(f"task {task!r}: TTS.inference is built for 'tts', 'ns' and 'sr'")
         for k in ("input_prompt_length", "seed", "tqdm", "use_lora", "dtype", "amp", "phonemize", "voice_convert", "split_text_by"):
             sampling_kwargs.pop(k, None)
         modality = self.modality(sampling_kwargs.pop("modality", "auto"))
@@ -171,6 +171,8 @@ class TTS:
         lines = text.split("\n") if isinstance(text, str) else list(text)
         lines = [l for l in lines if not isinstance(l, str) or l.strip()] or [""]
         prom = references
+        if task in ("ns", "sr"):                                                  # inference.py:489-493: the task token rides
+            prom = [task, prom]                                                   # in front of the prompt; the model task stays tts
         lang = self.encode_lang(language) if isinstance(language, str) else language
         prefix_context, history, out = None, [], []
         for n, line in enumerate(lines):
@@ -180,8 +182,11 @@ class TTS:
             if max_duration is not None:
                 per_line["max_duration"] = max_duration[n] if isinstance(max_duration, (list, tuple)) else max_duration
             if modality == "nar-len":
-                lens = self.model(**kw, task_list=["len"], max_duration=5)
-                lens = [int(max(l, 75) * duration_padding) for l in lens]         # inference.py:535-538 (75 frames per second)
+                if task in ("ns", "sr"):
+                    lens = [int(prom[1].shape[0])]                                # inference.py:527-528: as long as the input
+                else:
+                    lens = self.model(**kw, task_list=["len"], max_duration=5)
+                    lens = [int(max(l, 75) * duration_padding) for l in lens]     # inference.py:535-538 (75 frames per second)
                 if prefix_context is not None:
                     per_line["prefix_context"] = prefix_context
                 resps = self.model(**kw, task_list=["tts"], len_list=lens, **per_line)

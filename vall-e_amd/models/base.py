@@ -26,6 +26,11 @@ Sampled = namedtuple("Sampled", ["ids", "logits", "scores", "entropy"])         
 UNSUPPORTED_SAMPLERS = ("beam_width", "entropix_sampling", "prefix_silence", "layer_skip")
 
 
+# data.py:670-688 (get_task_symmap): rows of tasks_emb
+TASK_SYMMAP = {"tts": 0, "tts-c": 1, "ns": 2, "sr": 3, "tse": 4, "soe": 5, "mask": 6, "eoe": 7, "stt": 8,
+               "len": 0, "nse": 6, "cse": 6, "phn": 0, "un-phn": 0}
+
+
 def _round_up(a, b):
     return (a + b - 1) // b * b
 
@@ -319,18 +324,28 @@ class Base:
                 segs.append(("lang", rows1(off["lang"], _np(lang_list[i]))))
             segs.append(("quant_level", rows1(off["rvq"], np.array([q]))))
             if proms_list is not None and proms_list[i] is not None:
-                prom = proms_list[i]
-                if isinstance(prom, (list, tuple)):
-                    raise NotImplementedError("task tokens inside the prompt (tts-c/ns/sr) are outside this path")
-                prom = _np(prom)
-                if prom.ndim == 1:
-                    segs.append(("prom", rows1(off["prom0"], prom)))
-                else:
-                    n = 1 if q == 0 else q                                            # base.py:790-794
-                    r = np.full((prom.shape[0], 8), -1, dtype=np.int32)
-                    for l in range(n):
-                        r[:, l] = off[f"prom{l}"] + prom[:, l]
-                    segs.append(("prom", r))
+                # a prompt is a code tensor or a list of code tensors and task-token strings ([task, codes] for
+                # ns / sr, inference.py:489-493; base.py:780-794, :850-856).  The reference's position ids count only
+                # the tensors of a list (base.py:964-974), so n_tok < rows when task tokens are present.
+                plist = proms_list[i] if isinstance(proms_list[i], (list, tuple)) else [proms_list[i]]
+                parts_p, n_tok = [], 0
+                for prom in plist:
+                    if prom is None:
+                        continue
+                    if isinstance(prom, str):
+                        parts_p.append(rows1(off["task"], np.array([TASK_SYMMAP[prom]])))
+                        continue
+                    prom = _np(prom)
+                    n_tok += prom.shape[0]
+                    if prom.ndim == 1:
+                        parts_p.append(rows1(off["prom0"], prom))
+                    else:
+                        n = 1 if q == 0 else q                                        # base.py:790-794
+                        r = np.full((prom.shape[0], 8), -1, dtype=np.int32)
+                        for l in range(n):
+                            r[:, l] = off[f"prom{l}"] + prom[:, l]
+                        parts_p.append(r)
+                segs.append(("prom", np.concatenate(parts_p) if parts_p else np.zeros((0, 8), np.int32), n_tok))
             if task == "len" and len_list is not None and len_list[i] is not None:
                 segs.append(("len", rows1(off["len"], _np(len_list[i]))))
             resp = resps_list[i] if task != "len" else None
@@ -350,13 +365,17 @@ class Base:
                         r[:, l] = off[f"resp{l + 1}"] + resp[:, l]
                     segs.append(("resp", r))
             parts, pos = [], []
-            for j, (kind, r) in enumerate(segs):
+            for j, seg in enumerate(segs):
+                kind, r = seg[0], seg[1]
+                n_tok = seg[2] if len(seg) > 2 else r.shape[0]
                 if j:
                     parts.append(sep_row)
                 parts.append(r)
-                pos.append(np.arange(r.shape[0] + (0 if kind == out_kind else 1), dtype=np.int32))
+                pos.append(np.arange(n_tok + (0 if kind == out_kind else 1), dtype=np.int32))
             idx = np.concatenate(parts)
             pos = np.concatenate(pos)[: idx.shape[0]]
+            if pos.shape[0] < idx.shape[0]:                                           # base.py:988-990: tail filled with 1
+                pos = np.concatenate([pos, np.ones(idx.shape[0] - pos.shape[0], np.int32)])
             if self.unified_position_ids:
                 pos = np.arange(idx.shape[0], dtype=np.int32)
             idx_all.append(idx), pos_all.append(pos), lens.append(idx.shape[0])
