@@ -97,8 +97,11 @@ def test_unsupported_options_fail_loudly():
     m = host_model()
     with pytest.raises(NotImplementedError):
         m.sample_params(beam_width=4)
+    m.sample_params(mirostat_tau=3.0, mirostat_eta=0.1)                  # accepted and without effect, as in the reference
+    with pytest.raises(NotImplementedError):                            # (ar_nar.py:702-704 vs :804-808); an explicit state list is not
+        m.sample_params(mirostat=[{"n": 1024, "tau": 3.0, "eta": 0.1}])
     with pytest.raises(NotImplementedError):
-        m.sample_params(mirostat_tau=3.0)
+        m.sample_params(prefix_silence=0.5)
     sp = m.sample_params(temperature=1.0, min_temperature=0.5, dry_multiplier=0.8, dry_allowed_length=1)
     assert (sp.temperature64, sp.min_temperature64, sp.dry_multiplier, sp.dry_allowed_length) == (1.0, 0.5, 0.8, 1)
     sp = m.sample_params(temperature=0.7, min_temperature=0.7004)       # closer than 0.001: plain temperature (base.py:1389)
