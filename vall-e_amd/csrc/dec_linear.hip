@@ -175,11 +175,12 @@ static int dec_wave_launch(const DecWArgs& a, hipStream_t s) {
 
 // K-split of one 16-row tile over the waves of a workgroup.  Measured on the decode-layer chain (tools/micro_dec,
 // tools/run_dec_variants.sh, B = 16): 2 waves for K = 1024 and 8 waves for K = 4096 give 30.0 us per layer against
-// 31.8 us for (1, 4); more waves lose again to the LDS reduction.  VALLE_DEC_NWK / VALLE_DEC_NWK_DN override (dev).
-static int dec_variant() {
+// 31.8 us for (1, 4); more waves lose again to the LDS reduction; above 16 utterances K = 1024 stays on one wave
+// (B = 32: 40.1 vs 40.8 us per layer).  VALLE_DEC_NWK / VALLE_DEC_NWK_DN override (dev).
+static int dec_variant(int B) {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("VALLE_DEC_NWK"); v = e ? atoi(e) : 2; }
-    return v;
+    if (v < 0) { const char* e = getenv("VALLE_DEC_NWK"); v = e ? atoi(e) : 0; }
+    return v ? v : (B <= 16 ? 2 : 1);      // two 16-utterance tiles per wave (B > 16): one wave per tile is 40.1 vs 40.8 us
 }
 static int dec_variant_dn() {
     static int v = -1;
@@ -187,7 +188,7 @@ static int dec_variant_dn() {
     return v;
 }
 #define DEC_K1024(EPI, NORM) \
-    switch (dec_variant()) { \
+    switch (dec_variant(a.B)) { \
         case 1: return dec_wave_launch<EPI, 16, 1, NORM>(a, s); \
         case 2: return dec_wave_launch<EPI, 8, 2, NORM>(a, s); \
         case 4: return dec_wave_launch<EPI, 4, 4, NORM>(a, s); \
