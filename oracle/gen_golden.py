@@ -607,6 +607,37 @@ def scen_tiny_task_prompt():
     save("tiny_task_prompt", **d)
 
 
+def scen_tiny_raw_text():
+    """``text_list`` in place of ``phns_list`` (raw text ids through raw_text_emb; base.py:609-610, :841-842 -- what
+    inference.py:518-519 sends with phonemize=False): AR with guidance (the null pass then carries raw text too,
+    ar_nar.py:787-788) and the NAR levels."""
+    ref = rh.load_reference()
+    model, mcfg = get_ref_model("tiny")
+    n_text = model.raw_text_emb.weight.shape[0]
+    for seed in range(131, 150):
+        _, proms, langs = synth_batch(seed, 2, n_phn=10, n_prom=16, ragged=True)
+        g = torch.Generator().manual_seed(seed)
+        texts = [torch.cat([torch.tensor([1]), torch.randint(3, n_text, (n,), generator=g), torch.tensor([2])]).to(torch.int16) for n in (9, 13)]
+        kw = lambda: dict(task_list=["tts"] * 2, text_list=[t.clone() for t in texts], proms_list=[p.clone() for p in proms],
+                          lang_list=[l.clone() for l in langs], disable_tqdm=True, temperature=0.0)
+        with Recorder(ref) as rec, torch.inference_mode():
+            codes = model(**kw(), max_duration=10)
+            n_ar = len(rec.calls)
+            full = model(**kw(), resps_list=[c.clone() for c in codes])
+            codes_cfg = model(**kw(), max_duration=6, cfg_strength=2.0)
+        gap = min(top2_gap(r) for c in rec.calls[:n_ar] for r in c["logits"])
+        print(f"  [tiny_raw_text] seed {seed} AR min top-2 gap {gap:.3e}")
+        if gap > MIN_GAP:
+            break
+    else:
+        raise RuntimeError("tiny_raw_text: no seed with a usable margin")
+    d = input_arrays(texts, proms, langs)            # phn_* hold the raw text ids here
+    d.update(pack_list("ar_codes", codes)), d.update(pack_list("nar_codes", full)), d.update(pack_list("cfg_codes", codes_cfg))
+    d["first_logits"] = torch.stack(rec.calls[0]["logits"])
+    d["steps"], d["cfg_steps"], d["cfg_strength"], d["min_gap"] = np.int64(10), np.int64(6), np.float64(2.0), np.float64(gap)
+    save("tiny_raw_text", **d)
+
+
 def scen_full_b1():
     ref = rh.load_reference()
     phns, proms, langs = qnt_inputs()
@@ -662,6 +693,7 @@ SCENARIOS = {
     "tiny_noncausal": scen_tiny_noncausal,
     "tiny_ar_options": scen_tiny_ar_options,
     "tiny_task_prompt": scen_tiny_task_prompt,
+    "tiny_raw_text": scen_tiny_raw_text,
     "full_b1": scen_full_b1,
     "full_b3": scen_full_b3,
     "full_narlen": scen_full_narlen,

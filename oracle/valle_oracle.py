@@ -69,6 +69,14 @@ def _seg_tokens(ids):
     return int(ids.shape[0])
 
 
+class RawText:
+    """Marks an id tensor as raw text (the reference's ``text_list``: ids of the text tokenizer embedded by
+    ``raw_text_emb`` in place of the phonemes, base.py:609-610, :841-842; inference.py:518-519 with phonemize=False)."""
+
+    def __init__(self, ids):
+        self.ids = torch.as_tensor(ids).long()
+
+
 def plan_sequence(phn, lang, prom, resp, quant_level, *, timestep=False, task="tts", unified_pos=False, len_ids=None):
     """Ordered segments of one utterance + per-segment position ids.
 
@@ -79,7 +87,9 @@ def plan_sequence(phn, lang, prom, resp, quant_level, *, timestep=False, task="t
     if task not in ("tts", "len"):
         raise NotImplementedError("oracle covers the tts layout (AR, NAR, NAR-len) and the len task")
     segs = []
-    if phn is not None:
+    if isinstance(phn, RawText):
+        segs.append(Segment("text", phn.ids))
+    elif phn is not None:
         segs.append(Segment("phn", phn.long()))
     if lang is not None:
         segs.append(Segment("lang", lang.long()))
@@ -320,6 +330,8 @@ class Oracle:
         ids = seg.ids
         if seg.kind == "phn":
             return self.w["text_emb.weight"][ids]
+        if seg.kind == "text":
+            return self.w["raw_text_emb.weight"][ids]
         if seg.kind == "lang":
             return self.w["langs_emb.weight"][ids]
         if seg.kind == "quant_level":
@@ -509,7 +521,7 @@ class Oracle:
             phns = [torch.cat([p[:-1].long(), t[1:].long()]) for p, t in zip(prefix_text, phns)]
             seqs = [(r if r.dim() == 1 else r[:, 0]).long() for r in prefix_resps]
         stopped = [False] * B
-        null_phn = [torch.tensor([1, 2]) for _ in range(B)]
+        null_phn = [RawText([1, 2]) if isinstance(phns[i], RawText) else torch.tensor([1, 2]) for i in range(B)]   # ar_nar.py:787-788
         last_logits = []
         kv = [[None] * B for _ in range(self.L)] if use_cache else None
         for n in range(max_duration // max(1, self.causal_size)):
@@ -569,13 +581,16 @@ class Oracle:
         B = len(resps)
         prev = [r[:, None] if r.dim() == 1 else r for r in resps]
         prev = [p.long() for p in prev]
-        null_phn = [torch.tensor([1, 2]) for _ in range(B)]
+        null_phn = [RawText([1, 2]) if isinstance(phns[i], RawText) else torch.tensor([1, 2]) for i in range(B)]
         for _ in range(max_levels):
             level = prev[0].shape[-1]
             if level >= max_levels + 1:
                 break
             R = [p.shape[0] for p in prev]
-            logits = self.forward(self._plans(phns, langs, proms, prev, level), rows=R)
+            # quirk: the level loop hands only phns_list to inputs() (ar_nar.py:544-551), so raw text (text_list) is
+            # absent from the conditional pass of every NAR level; the null pass of the guidance does get it (:560-562)
+            cond = [None if isinstance(p, RawText) else p for p in phns]
+            logits = self.forward(self._plans(cond, langs, proms, prev, level), rows=R)
             if cfg_strength > 0:
                 null = self.forward(self._plans(null_phn, langs, None, prev, level), rows=R)
                 logits = cfg_combine(logits, null, cfg_strength, R, cfg_rescale)
@@ -608,7 +623,7 @@ class Oracle:
             prefix = [(r if r.dim() == 1 else r[:, 0]).long() for r in prefix_context[1]]
         resps = [torch.full((n,), self.mask_token, dtype=torch.int64) for n in lens]
         scores = [torch.ones(n, dtype=torch.float32) for n in lens]
-        null_phn = [torch.tensor([1, 2]) for _ in range(B)]
+        null_phn = [RawText([1, 2]) if isinstance(phns[i], RawText) else torch.tensor([1, 2]) for i in range(B)]
         for step, t in enumerate(torch.linspace(start, end, max_steps)):
             noise_p = math.cos(t * math.pi * 0.5)
             mask_p = noise_p + (1.0 / (max_steps * 2) if remask else 0)

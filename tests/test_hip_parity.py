@@ -452,6 +452,24 @@ def test_tiny_task_token_prompt(gpu_device):
         np.testing.assert_array_equal(lines[0].cpu().numpy(), z[f"nar_codes_{b}"])
 
 
+def test_tiny_raw_text_inputs(gpu_device):
+    """text_list in place of phns_list (base.py:609-610, :841-842; inference.py:518-519 with phonemize=False):
+    AR, guided AR and NAR codes == the reference's."""
+    z = load_golden("tiny_raw_text")
+    texts, proms, langs = golden_inputs(z)
+    B = len(texts)
+    m = hip_model("tiny")
+    kw = dict(task_list=["tts"] * B, text_list=texts, proms_list=proms, lang_list=langs, temperature=0.0)
+    codes, logits = m(**kw, max_duration=int(z["steps"]), return_logits=True)
+    torch.testing.assert_close(logits[0].cpu(), torch.from_numpy(z["first_logits"]), rtol=1e-3, atol=1e-3)
+    full = m(**kw, resps_list=[c.clone() for c in codes])
+    cfg = m(**kw, max_duration=int(z["cfg_steps"]), cfg_strength=float(z["cfg_strength"]))
+    for b in range(B):
+        np.testing.assert_array_equal(codes[b].cpu().numpy(), z[f"ar_codes_{b}"])
+        np.testing.assert_array_equal(full[b].cpu().numpy(), z[f"nar_codes_{b}"])
+        np.testing.assert_array_equal(cfg[b].cpu().numpy(), z[f"cfg_codes_{b}"])
+
+
 def test_edge_shapes_match_oracle(gpu_device):
     """Smallest and most ragged shapes: no prompt, one-phoneme text, one AR step, one-frame NAR, batch of one."""
     m, o = hip_model("tiny"), oracle("tiny")

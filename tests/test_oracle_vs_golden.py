@@ -302,6 +302,25 @@ def test_tiny_task_token_prompt():
         np.testing.assert_array_equal(full[b].numpy(), z[f"nar_codes_{b}"])
 
 
+def test_tiny_raw_text_inputs():
+    """text_list in place of phns_list (base.py:609-610, :841-842): raw_text_emb rows, also in the null pass of the
+    guidance (ar_nar.py:787-788)."""
+    z = load_golden("tiny_raw_text")
+    texts, proms, langs = golden_inputs(z)
+    B = len(texts)
+    texts = [vo.RawText(t) for t in texts]
+    o = make_oracle("tiny")
+    codes, logits = o.ar(texts, proms, langs, max_duration=int(z["steps"]), temperature=0.0, return_logits=True)
+    assert_close(logits[0], z["first_logits"], 5e-4, 5e-4)
+    for b in range(B):
+        np.testing.assert_array_equal(codes[b].numpy(), z[f"ar_codes_{b}"])
+    full = o.nar(texts, proms, langs, codes, temperature=0.0)
+    cfg = o.ar(texts, proms, langs, max_duration=int(z["cfg_steps"]), temperature=0.0, cfg_strength=float(z["cfg_strength"]))
+    for b in range(B):
+        np.testing.assert_array_equal(full[b].numpy(), z[f"nar_codes_{b}"])
+        np.testing.assert_array_equal(cfg[b].numpy(), z[f"cfg_codes_{b}"])
+
+
 def test_full_b1_configs0():
     """BASELINE.json configs[0]: repo-default model, data/qnt.enc prompt, greedy AR + NAR."""
     _ar_nar("full", "full_b1")

@@ -162,8 +162,9 @@ class TTS:
         a list (one value per line)."""
         if task not in ("tts", "ns", "sr"):
             raise NotImplementedError(f"task {task!r}: TTS.inference is built for 'tts', 'ns' and 'sr'")
-        for k in ("input_prompt_length", "seed", "tqdm", "use_lora", "dtype", "amp", "phonemize", "voice_convert", "split_text_by"):
+        for k in ("input_prompt_length", "seed", "tqdm", "use_lora", "dtype", "amp", "voice_convert", "split_text_by"):
             sampling_kwargs.pop(k, None)
+        phonemize = sampling_kwargs.pop("phonemize", True)     # False: lines are raw-text ids, sent as text_list (inference.py:518-519)
         modality = self.modality(sampling_kwargs.pop("modality", "auto"))
         duration_padding = sampling_kwargs.pop("duration_padding", 1.05)
         context_history = int(sampling_kwargs.pop("context_history", 0))
@@ -176,8 +177,14 @@ class TTS:
         lang = self.encode_lang(language) if isinstance(language, str) else language
         prefix_context, history, out = None, [], []
         for n, line in enumerate(lines):
-            phns = self.encode_text(line)
-            kw = dict(phns_list=[phns], proms_list=[prom], lang_list=[lang])
+            if phonemize:
+                phns = self.encode_text(line)
+                kw = dict(phns_list=[phns], proms_list=[prom], lang_list=[lang])
+            else:
+                if isinstance(line, str):
+                    raise NotImplementedError("phonemize=False takes ids of the reference's text tokenizer, not strings")
+                phns = torch.as_tensor(line)
+                kw = dict(text_list=[phns], proms_list=[prom], lang_list=[lang])
             per_line = dict(sampling_kwargs)
             if max_duration is not None:
                 per_line["max_duration"] = max_duration[n] if isinstance(max_duration, (list, tuple)) else max_duration

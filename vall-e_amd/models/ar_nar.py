@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .. import _lib as L
-from .base import Base, Logits, _np, _round_up
+from .base import Base, Logits, RawText, _np, _round_up
 
 
 def convert_kwargs(kwargs, prefix):
@@ -67,8 +67,10 @@ class AR_NAR(Base):
     # ------------------------------------------------------------------------------ dispatch
     def forward(self, task_list=None, phns_list=None, proms_list=None, resps_list=None, lang_list=None, tone_list=None,
                 len_list=None, text_list=None, training=None, disable_tqdm=False, use_lora=None, **sampling_kwargs):
-        if text_list is not None or tone_list is not None:
-            raise NotImplementedError("raw-text / tone inputs are outside the built path")
+        if tone_list is not None:
+            raise NotImplementedError("tone inputs are outside the built path")
+        if text_list is not None and phns_list is None:                       # raw text in place of phonemes (base.py:609-610):
+            phns_list = [None if t is None else RawText(t) for t in text_list]   # one list travels through every path
         if task_list is not None and any(t not in ("tts", "len") for t in task_list):
             raise NotImplementedError(f"tasks {sorted(set(task_list))}: only 'tts' (AR, NAR, NAR-len) and 'len' are built")
         if training:
@@ -84,6 +86,11 @@ class AR_NAR(Base):
                                lang_list=lang_list, **sampling_kwargs)
 
     __call__ = forward
+
+    @staticmethod
+    def _null_text(phns_list):
+        """The null condition's text <bos><eos>, as phonemes or as raw text like the input (ar_nar.py:787-788)."""
+        return [RawText(torch.tensor([1, 2])) if isinstance(p, RawText) else torch.tensor([1, 2]) for p in phns_list]
 
     # ----------------------------------------------------------------------------------- len
     def forward_len(self, phns_list, proms_list=None, lang_list=None, return_logits=False):
@@ -149,13 +156,15 @@ class AR_NAR(Base):
             prefix = [_np(p)[:, 0] for p in proms_list]
             proms_list = [torch.zeros(0, dtype=torch.int16) for _ in range(B)]
         if prefix_context is not None:                                        # ar_nar.py:736-742
+            if any(isinstance(p, RawText) for p in phns_list):
+                raise TypeError("prefix_context splices phoneme lists; the reference fails the same way with text_list")
             prefix_text, prefix_resps, prefix_lens = prefix_context
             phns_list = [torch.cat([torch.as_tensor(p)[:-1], torch.as_tensor(t)[1:]]) for p, t in zip(prefix_text, phns_list)]
             prefix = [(_np(r) if _np(r).ndim == 1 else _np(r)[:, 0]) for r in prefix_resps]
 
         passes = [(phns_list, proms_list)]
         if cfg_strength > 0:                                                  # null text / no prompt (ar_nar.py:744-745)
-            passes.append(([torch.tensor([1, 2]) for _ in range(B)], None))
+            passes.append((self._null_text(phns_list), None))
 
         V = self.cls_tokens[0]
         ld = _round_up(V, 8)
@@ -340,7 +349,10 @@ class AR_NAR(Base):
         # bookkeeping done on the host; one device->host copy here and one per level (the new column)
         prev = _host_codes(resps_list)
         sp = self.sample_params(**kw)
-        null_text = [torch.tensor([1, 2]) for _ in range(B)]
+        null_text = self._null_text(phns_list)
+        # quirk: the reference's level loop hands only phns_list to inputs() (ar_nar.py:544-551), so raw text
+        # (text_list) is absent from the conditional pass of every NAR level; the null pass does get it (:560-562)
+        cond_text = [None if isinstance(p, RawText) else p for p in phns_list]
         level0 = prev[0].shape[-1]
         R = [p.shape[0] for p in prev]
         total = int(sum(R))
@@ -361,7 +373,7 @@ class AR_NAR(Base):
                 return
             q = levels[n]
             resp_q = [x[:, :q] for x in ph]
-            plan = self.plan(phns_list, lang_list, proms_list, resp_q, q)
+            plan = self.plan(cond_text, lang_list, proms_list, resp_q, q)
             rows, _ = self.tail_rows(plan, R)
             plans[n] = (plan, rows, self.upload_plan(plan, rows))
             if cfg_strength > 0:
@@ -431,7 +443,7 @@ class AR_NAR(Base):
         codes = torch.full((total,), self.mask_token, dtype=torch.int32, device=dev)
         scores = torch.ones(total, dtype=torch.float32, device=dev)
         is_masked = torch.empty(total, dtype=torch.uint8, device=dev)
-        null_text = [torch.tensor([1, 2]) for _ in range(B)]
+        null_text = self._null_text(phns_list)
         V = self.cls_tokens[self.cls_names.index("NAR:0:0")]
         stream = L.stream_ptr(dev)
         # the sequence layout does not change between demasking steps: both plans are built and uploaded once, and

@@ -31,6 +31,15 @@ TASK_SYMMAP = {"tts": 0, "tts-c": 1, "ns": 2, "sr": 3, "tse": 4, "soe": 5, "mask
                "len": 0, "nse": 6, "cse": 6, "phn": 0, "un-phn": 0}
 
 
+class RawText:
+    """Marks an id tensor as raw text -- the reference's ``text_list`` (ids of the text tokenizer, embedded by
+    ``raw_text_emb`` in place of the phonemes: base.py:609-610, :841-842; inference.py:518-519 with phonemize=False).
+    ``forward(text_list=...)`` wraps its entries so that one list travels through every call path."""
+
+    def __init__(self, ids):
+        self.ids = ids
+
+
 def _round_up(a, b):
     return (a + b - 1) // b * b
 
@@ -148,7 +157,7 @@ class Base:
     def _table_offsets(self):
         """Row offsets of every embedding table inside the one concatenated table."""
         spec = self.state_dict_spec()
-        order = [("text", "text_emb.weight"), ("rvq", "rvq_l_emb.weight"), ("lang", "langs_emb.weight"),
+        order = [("text", "text_emb.weight"), ("raw_text", "raw_text_emb.weight"), ("rvq", "rvq_l_emb.weight"), ("lang", "langs_emb.weight"),
                  ("task", "tasks_emb.weight"), ("len", "len_emb.weight"), ("tone", "tones_emb.weight"), ("sep", "sep")]
         order += [(f"prom{l}", f"proms_emb.embeddings.{l}.weight") for l in range(self.n_resp_levels)]
         order += [(f"resp{l}", f"resps_emb.embeddings.{l}.weight") for l in range(len(self.emb_tokens))]
@@ -237,8 +246,10 @@ class Base:
         """The reference's per-utterance list of (name, value) tuples for the TTS layout (base.py:560-649):
         task, phn, lang, quant_level, prom, resp, classifier_level -- and for the ``len`` task (base.py:652-683):
         task, phn, lang, quant_level, prom, len, classifier_level -- accepted by ``forward_super``."""
-        if text_list is not None or tone_list is not None:
-            raise NotImplementedError("raw-text / tone inputs are outside the built path")
+        if tone_list is not None:
+            raise NotImplementedError("tone inputs are outside the built path")
+        if phns_list is None and text_list is not None:
+            phns_list = [None if t is None else RawText(t) for t in text_list]
         first = next(l for l in (phns_list, proms_list, resps_list) if l)
         B = len(first)
         out = [[] for _ in range(B)]
@@ -252,7 +263,7 @@ class Base:
             timestep = time_list[i] if time_list is not None else None
             out[i].append(("task", task))
             if phns_list is not None and phns_list[i] is not None:
-                out[i].append(("phn", phns_list[i]))
+                out[i].append(("text", phns_list[i].ids) if isinstance(phns_list[i], RawText) else ("phn", phns_list[i]))
             if "lang" in self.capabilities and lang_list is not None and lang_list[i] is not None:
                 out[i].append(("lang", lang_list[i]))
             out[i].append(("quant_level", torch.tensor([q], dtype=torch.int16)))
@@ -278,7 +289,8 @@ class Base:
 
     def plan_from_inputs(self, inputs):
         """``inputs()`` tuples -> Plan.  One classifier level per batch (one head per dense pass)."""
-        col = {k: [dict((n, v) for n, v in item if n != "task").get(k) for item in inputs] for k in ("phn", "lang", "prom", "resp", "len")}
+        col = {k: [dict((n, v) for n, v in item if n != "task").get(k) for item in inputs] for k in ("phn", "text", "lang", "prom", "resp", "len")}
+        col["phn"] = [p if p is not None else (None if t is None else RawText(t)) for p, t in zip(col["phn"], col["text"])]
         levels = {dict(item)["classifier_level"] for item in inputs}
         qs = {int(dict(item)["quant_level"][0]) for item in inputs}
         if len(levels) != 1 or len(qs) != 1:
@@ -318,7 +330,11 @@ class Base:
 
         for i in range(B):
             segs = []
-            if phns_list is not None and phns_list[i] is not None:
+            if phns_list is not None and isinstance(phns_list[i], RawText):             # base.py:609-610, :841-842
+                if "raw_text" not in off:
+                    raise Exception("text_list given but the model has no raw_text_emb")
+                segs.append(("text", rows1(off["raw_text"], _np(phns_list[i].ids))))
+            elif phns_list is not None and phns_list[i] is not None:
                 segs.append(("phn", rows1(off["text"], _np(phns_list[i]))))
             if "lang" in self.capabilities and lang_list is not None and lang_list[i] is not None:
                 segs.append(("lang", rows1(off["lang"], _np(lang_list[i]))))
