@@ -97,7 +97,7 @@ def get_ref_model(kind, dtype=torch.float32, **synth_kw):
     if key in _models:
         return _models[key]
     mcfg = {"full": vcfg.repo_default_model, "tiny": vcfg.tiny_model, "tiny_len": vcfg.tiny_len_model,
-            "tiny_nc": vcfg.tiny_nc_model}[kind]()
+            "tiny_nc": vcfg.tiny_nc_model, "tiny_tone": vcfg.tiny_tone_model}[kind]()
     model = rh.build_reference_model(size=mcfg.size, capabilities=list(mcfg.capabilities),
                                      noncausal_masks=mcfg.experimental.noncausal_masks)
     assert model.noncausal_masks == mcfg.experimental.noncausal_masks
@@ -638,6 +638,43 @@ def scen_tiny_raw_text():
     save("tiny_raw_text", **d)
 
 
+def scen_tiny_tone():
+    """``tone_list`` on a model with the ``tone`` capability (base.py:623-624, :672-673, :857-858): a tone token between
+    prompt and response in every pass -- AR, the guidance's null pass, NAR levels, the len task."""
+    ref = rh.load_reference()
+    model, mcfg = get_ref_model("tiny_tone")
+    assert "tone" in model.capabilities
+    for seed in range(151, 170):
+        phns, proms, langs = synth_batch(seed, 2, n_phn=10, n_prom=16, ragged=True)
+        tones = [torch.tensor([0], dtype=torch.uint8) for _ in range(2)]
+        kw = lambda: dict(phns_list=[p.clone() for p in phns], proms_list=[p.clone() for p in proms], lang_list=[l.clone() for l in langs],
+                          tone_list=[t.clone() for t in tones], disable_tqdm=True)
+        with Recorder(ref) as rec, torch.inference_mode():
+            codes = model(task_list=["tts"] * 2, **kw(), max_duration=9, temperature=0.0)
+            n_ar = len(rec.calls)
+            full = model(task_list=["tts"] * 2, **kw(), resps_list=[c.clone() for c in codes], temperature=0.0, max_levels=2)
+            codes_cfg = model(task_list=["tts"] * 2, **kw(), max_duration=5, temperature=0.0, cfg_strength=2.0)
+            n_len0 = len(rec.calls)
+            lens = model(task_list=["len"] * 2, **kw(), max_duration=5)
+            no_tone = model(task_list=["tts"] * 2, phns_list=[p.clone() for p in phns], proms_list=[p.clone() for p in proms],
+                            lang_list=[l.clone() for l in langs], disable_tqdm=True, max_duration=9, temperature=0.0)
+        gap = min(top2_gap(r) for c in rec.calls[:n_ar] for r in c["logits"])
+        differs = any(not torch.equal(a, b) for a, b in zip(codes, no_tone))
+        print(f"  [tiny_tone] seed {seed} AR min top-2 gap {gap:.3e}, tone changes the codes: {differs}, lens {lens}")
+        if gap > MIN_GAP and differs:
+            break
+    else:
+        raise RuntimeError("tiny_tone: no usable seed")
+    d = input_arrays(phns, proms, langs)
+    d.update(pack_list("tone", tones))
+    d.update(pack_list("ar_codes", codes)), d.update(pack_list("nar_codes", full)), d.update(pack_list("cfg_codes", codes_cfg))
+    d["first_logits"] = torch.stack(rec.calls[0]["logits"])
+    d["len_first_logits"] = torch.stack(rec.calls[n_len0]["logits"])
+    d["lens"] = np.array(lens, dtype=np.int64)
+    d["steps"], d["cfg_steps"], d["cfg_strength"], d["nar_max_levels"], d["min_gap"] = np.int64(9), np.int64(5), np.float64(2.0), np.int64(2), np.float64(gap)
+    save("tiny_tone", **d)
+
+
 def scen_full_b1():
     ref = rh.load_reference()
     phns, proms, langs = qnt_inputs()
@@ -694,6 +731,7 @@ SCENARIOS = {
     "tiny_ar_options": scen_tiny_ar_options,
     "tiny_task_prompt": scen_tiny_task_prompt,
     "tiny_raw_text": scen_tiny_raw_text,
+    "tiny_tone": scen_tiny_tone,
     "full_b1": scen_full_b1,
     "full_b3": scen_full_b3,
     "full_narlen": scen_full_narlen,

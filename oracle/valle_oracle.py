@@ -77,7 +77,7 @@ class RawText:
         self.ids = torch.as_tensor(ids).long()
 
 
-def plan_sequence(phn, lang, prom, resp, quant_level, *, timestep=False, task="tts", unified_pos=False, len_ids=None):
+def plan_sequence(phn, lang, prom, resp, quant_level, *, timestep=False, task="tts", unified_pos=False, len_ids=None, tone=None):
     """Ordered segments of one utterance + per-segment position ids.
 
     TTS order: phn, lang, quant_level, prom, resp (base.py:605-649); every segment but the
@@ -100,6 +100,8 @@ def plan_sequence(phn, lang, prom, resp, quant_level, *, timestep=False, task="t
             segs.append(Segment("prom", [p if isinstance(p, str) else p.long() for p in prom if p is not None]))
         else:
             segs.append(Segment("prom", prom.long()))
+    if tone is not None:                                                  # base.py:623-624, :672-673 (capability "tone")
+        segs.append(Segment("tone", tone.long()))
     if timestep:
         head = "NAR:0:0"
     if task == "len":
@@ -318,6 +320,8 @@ class Oracle:
             torch.set_num_threads(threads)
 
     # -- embeddings (base.py:774-922) ---------------------------------------------
+    tones = None     # tone_list of the current call (every pass of a call carries the same list)
+
     def _audio_sum(self, table_prefix, first, codes, n):
         acc = None
         for l in range(n):
@@ -338,6 +342,8 @@ class Oracle:
             return self.w["rvq_l_emb.weight"][ids]
         if seg.kind == "len":
             return self.w["len_emb.weight"][ids]
+        if seg.kind == "tone":
+            return self.w["tones_emb.weight"][ids]
         if seg.kind == "prom" and isinstance(ids, list):                             # base.py:780-794, :850-856
             parts = []
             for p in ids:
@@ -467,9 +473,10 @@ class Oracle:
 
     def _plans(self, phns, langs, proms, resps, q, timestep=False):
         B = len(resps)
+        tones = self.tones if "tone" in self.cfg.capabilities else None  # set by the caller for the duration of a call
         return [plan_sequence(None if phns is None else phns[i], None if langs is None else langs[i],
                               None if proms is None else proms[i], resps[i], q, timestep=timestep,
-                              unified_pos=self.unified_pos) for i in range(B)]
+                              unified_pos=self.unified_pos, tone=None if tones is None else tones[i]) for i in range(B)]
 
     # -- duration prediction (ar_nar.py:640-692, len task) ------------------------------------
     def predict_len(self, phns, proms, langs, *, return_logits=False):
@@ -482,8 +489,10 @@ class Oracle:
         stopped = [False] * B
         kept = []
         for _ in range(10):
+            tones = self.tones if "tone" in self.cfg.capabilities else None
             plans = [plan_sequence(phns[i], None if langs is None else langs[i], None if proms is None else proms[i],
-                                   None, 0, task="len", unified_pos=self.unified_pos, len_ids=seqs[i]) for i in range(B)]
+                                   None, 0, task="len", unified_pos=self.unified_pos, len_ids=seqs[i],
+                                   tone=None if tones is None else tones[i]) for i in range(B)]
             logits = self.forward(plans, rows=[1] * B)
             if return_logits:
                 kept.append(torch.stack([l[-1].float() for l in logits]))

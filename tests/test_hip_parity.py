@@ -470,6 +470,34 @@ def test_tiny_raw_text_inputs(gpu_device):
         np.testing.assert_array_equal(cfg[b].cpu().numpy(), z[f"cfg_codes_{b}"])
 
 
+def test_tiny_tone_inputs(gpu_device):
+    """tone_list with the ``tone`` capability (base.py:623-624, :672-673): AR, guided AR, NAR levels, len task ==
+    the reference's; without the capability the list is ignored, as in the reference."""
+    z = load_golden("tiny_tone")
+    phns, proms, langs = golden_inputs(z)
+    B = len(phns)
+    tones = [torch.from_numpy(z[f"tone_{i}"]) for i in range(B)]
+    m = hip_model("tiny_tone")
+    kw = dict(phns_list=phns, proms_list=proms, lang_list=langs, tone_list=tones)
+    codes, logits = m(task_list=["tts"] * B, **kw, max_duration=int(z["steps"]), temperature=0.0, return_logits=True)
+    torch.testing.assert_close(logits[0].cpu(), torch.from_numpy(z["first_logits"]), rtol=1e-3, atol=1e-3)
+    full = m(task_list=["tts"] * B, **kw, resps_list=[c.clone() for c in codes], temperature=0.0, max_levels=int(z["nar_max_levels"]))
+    cfg = m(task_list=["tts"] * B, **kw, max_duration=int(z["cfg_steps"]), temperature=0.0, cfg_strength=float(z["cfg_strength"]))
+    lens = m(task_list=["len"] * B, **kw, max_duration=5)
+    for b in range(B):
+        np.testing.assert_array_equal(codes[b].cpu().numpy(), z[f"ar_codes_{b}"])
+        np.testing.assert_array_equal(full[b].cpu().numpy(), z[f"nar_codes_{b}"])
+        np.testing.assert_array_equal(cfg[b].cpu().numpy(), z[f"cfg_codes_{b}"])
+    assert lens == [int(x) for x in z["lens"]]
+    z0 = load_golden("tiny_ar_nar")                  # a model without the capability ignores the list (base.py:623)
+    p0, r0, l0 = golden_inputs(z0)
+    m0 = hip_model("tiny")
+    c0 = m0(task_list=["tts"] * len(p0), phns_list=p0, proms_list=r0, lang_list=l0, tone_list=[torch.tensor([0])] * len(p0),
+            max_duration=int(z0["steps"]), temperature=0.0)
+    for b in range(len(p0)):
+        np.testing.assert_array_equal(c0[b].cpu().numpy(), z0[f"ar_codes_{b}"])
+
+
 def test_edge_shapes_match_oracle(gpu_device):
     """Smallest and most ragged shapes: no prompt, one-phoneme text, one AR step, one-frame NAR, batch of one."""
     m, o = hip_model("tiny"), oracle("tiny")

@@ -321,6 +321,29 @@ def test_tiny_raw_text_inputs():
         np.testing.assert_array_equal(cfg[b].numpy(), z[f"cfg_codes_{b}"])
 
 
+def test_tiny_tone_inputs():
+    """tone_list with the ``tone`` capability (base.py:623-624, :672-673): AR, guided AR, NAR levels, len task."""
+    z = load_golden("tiny_tone")
+    phns, proms, langs = golden_inputs(z)
+    B = len(phns)
+    o = make_oracle("tiny_tone")
+    o.tones = [torch.from_numpy(z[f"tone_{i}"]) for i in range(B)]
+    codes, logits = o.ar(phns, proms, langs, max_duration=int(z["steps"]), temperature=0.0, return_logits=True)
+    assert_close(logits[0], z["first_logits"], 5e-4, 5e-4)
+    full = o.nar(phns, proms, langs, codes, temperature=0.0, max_levels=int(z["nar_max_levels"]))
+    cfg = o.ar(phns, proms, langs, max_duration=int(z["cfg_steps"]), temperature=0.0, cfg_strength=float(z["cfg_strength"]))
+    lens, kept, _ = o.predict_len(phns, proms, langs, return_logits=True)
+    for b in range(B):
+        np.testing.assert_array_equal(codes[b].numpy(), z[f"ar_codes_{b}"])
+        np.testing.assert_array_equal(full[b].numpy(), z[f"nar_codes_{b}"])
+        np.testing.assert_array_equal(cfg[b].numpy(), z[f"cfg_codes_{b}"])
+    assert lens == [int(x) for x in z["lens"]]
+    assert_close(kept[0], z["len_first_logits"], 5e-4, 5e-4)
+    o.tones = None                                   # without the list the codes differ (the golden's inputs were chosen so)
+    plain = o.ar(phns, proms, langs, max_duration=int(z["steps"]), temperature=0.0)
+    assert any((plain[b].numpy() != z[f"ar_codes_{b}"]).any() for b in range(B))
+
+
 def test_full_b1_configs0():
     """BASELINE.json configs[0]: repo-default model, data/qnt.enc prompt, greedy AR + NAR."""
     _ar_nar("full", "full_b1")

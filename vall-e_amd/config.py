@@ -143,6 +143,13 @@ def tiny_len_model(**kw) -> Model:
     return m
 
 
+def tiny_tone_model(**kw) -> Model:
+    """``tiny_len_model`` with the ``tone`` capability: a tone token between prompt and response (base.py:623-624)."""
+    m = tiny_len_model(**kw)
+    m.capabilities = ["ar", "nar", "len", "tone"]
+    return m
+
+
 def tiny_nc_model(**kw) -> Model:
     """Tiny sibling of the published ``ar+nar-len-llama-8`` switches: ``len`` head and ``noncausal_masks``
     (NAR levels attend in both directions, base.py:1230-1233)."""

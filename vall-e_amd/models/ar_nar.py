@@ -67,8 +67,16 @@ class AR_NAR(Base):
     # ------------------------------------------------------------------------------ dispatch
     def forward(self, task_list=None, phns_list=None, proms_list=None, resps_list=None, lang_list=None, tone_list=None,
                 len_list=None, text_list=None, training=None, disable_tqdm=False, use_lora=None, **sampling_kwargs):
-        if tone_list is not None:
-            raise NotImplementedError("tone inputs are outside the built path")
+        # tone tokens enter a sequence only with the "tone" capability (base.py:623-624); every pass the reference plans
+        # for this call -- conditional, null, len -- carries the same list, so it is kept for the duration of the call
+        self._call_tones = tone_list if "tone" in self.capabilities else None
+        try:
+            return self._forward(task_list, phns_list, proms_list, resps_list, lang_list, len_list, text_list, training,
+                                 **sampling_kwargs)
+        finally:
+            self._call_tones = None
+
+    def _forward(self, task_list, phns_list, proms_list, resps_list, lang_list, len_list, text_list, training, **sampling_kwargs):
         if text_list is not None and phns_list is None:                       # raw text in place of phonemes (base.py:609-610):
             phns_list = [None if t is None else RawText(t) for t in text_list]   # one list travels through every path
         if task_list is not None and any(t not in ("tts", "len") for t in task_list):
@@ -76,9 +84,10 @@ class AR_NAR(Base):
         if training:
             raise NotImplementedError("training is out of scope")
         if training is None and phns_list is not None and resps_list is not None:
-            levels = {(_np(r).shape[-1] if _np(r).ndim > 1 else 1) for r in resps_list}
-            if next(iter(levels)) == self.n_resp_levels:                    # ar_nar.py:927-931
-                raise NotImplementedError("resps with all levels means training in the reference; out of scope")
+            levels = {int(r.shape[-1]) for r in resps_list}                # ar_nar.py:927-931: shape[-1] also of a 1-D level-0
+            if next(iter(levels)) == self.n_resp_levels:                    # sequence -- exactly 8 frames count as "all levels"
+                raise NotImplementedError("resps whose last dimension equals the level count mean training in the reference "
+                                          "(also a 1-D sequence of exactly that many frames); out of scope")
         if (len_list is not None or resps_list is not None) and phns_list is not None:
             return self.forward_nar(task_list=task_list, phns_list=phns_list, proms_list=proms_list, resps_list=resps_list,
                                     lang_list=lang_list, len_list=len_list, **sampling_kwargs)

@@ -246,8 +246,6 @@ class Base:
         """The reference's per-utterance list of (name, value) tuples for the TTS layout (base.py:560-649):
         task, phn, lang, quant_level, prom, resp, classifier_level -- and for the ``len`` task (base.py:652-683):
         task, phn, lang, quant_level, prom, len, classifier_level -- accepted by ``forward_super``."""
-        if tone_list is not None:
-            raise NotImplementedError("tone inputs are outside the built path")
         if phns_list is None and text_list is not None:
             phns_list = [None if t is None else RawText(t) for t in text_list]
         first = next(l for l in (phns_list, proms_list, resps_list) if l)
@@ -270,6 +268,8 @@ class Base:
             level = "AR:0:0" if q == 0 else f"NAR:{q-1}:{q}"
             if proms_list is not None and proms_list[i] is not None:
                 out[i].append(("prom", proms_list[i]))
+            if "tone" in self.capabilities and tone_list is not None and tone_list[i] is not None:     # base.py:623-624, :672-673
+                out[i].append(("tone", tone_list[i]))
             if task == "len":
                 if "len" not in self.cls_names:                              # base.py:654-655
                     raise Exception("Requesting task `len` but corresponding embedding is not defined.")
@@ -289,7 +289,8 @@ class Base:
 
     def plan_from_inputs(self, inputs):
         """``inputs()`` tuples -> Plan.  One classifier level per batch (one head per dense pass)."""
-        col = {k: [dict((n, v) for n, v in item if n != "task").get(k) for item in inputs] for k in ("phn", "text", "lang", "prom", "resp", "len")}
+        col = {k: [dict((n, v) for n, v in item if n != "task").get(k) for item in inputs] for k in ("phn", "text", "lang", "prom", "tone", "resp", "len")}
+        tones = col["tone"] if any(t is not None for t in col["tone"]) else None
         col["phn"] = [p if p is not None else (None if t is None else RawText(t)) for p, t in zip(col["phn"], col["text"])]
         levels = {dict(item)["classifier_level"] for item in inputs}
         qs = {int(dict(item)["quant_level"][0]) for item in inputs}
@@ -300,15 +301,15 @@ class Base:
             return self.plan(col["phn"] if any(p is not None for p in col["phn"]) else None,
                              col["lang"] if any(p is not None for p in col["lang"]) else None,
                              col["prom"] if any(p is not None for p in col["prom"]) else None,
-                             [None] * len(inputs), q, task="len", len_list=col["len"])
+                             [None] * len(inputs), q, task="len", len_list=col["len"], tone_list=tones)
         resps = col["resp"] if any(r is not None for r in col["resp"]) else [None] * len(inputs)
         return self.plan(col["phn"] if any(p is not None for p in col["phn"]) else None,
                          col["lang"] if any(p is not None for p in col["lang"]) else None,
                          col["prom"] if any(p is not None for p in col["prom"]) else None,
-                         resps, q, timestep=(level == "NAR:0:0"))
+                         resps, q, timestep=(level == "NAR:0:0"), tone_list=tones)
 
     def plan(self, phns_list, lang_list, proms_list, resps_list, quant_level, *, timestep=False, task="tts",
-             len_list=None) -> Plan:
+             len_list=None, tone_list=None) -> Plan:
         """TTS layout phn, lang, quant_level, prom, resp with a ``sep`` row between segments
         (base.py:603-649, :101-110); classifier level per base.py:618/:628; position ids restart per
         segment, non-output segments count their trailing sep (base.py:984).  task "len" (base.py:652-683):
@@ -319,6 +320,8 @@ class Base:
             raise Exception("Requesting task `len` but corresponding embedding is not defined.")
         B = len(resps_list)
         q = quant_level
+        if tone_list is None:                         # the call's tone list (AR_NAR.forward keeps it for every pass it plans)
+            tone_list = getattr(self, "_call_tones", None)
         idx_all, pos_all, lens, out_len = [], [], [], []
         sep_row = np.full((1, 8), -1, dtype=np.int32)
         sep_row[0, 0] = off["sep"]
@@ -362,6 +365,8 @@ class Base:
                             r[:, l] = off[f"prom{l}"] + prom[:, l]
                         parts_p.append(r)
                 segs.append(("prom", np.concatenate(parts_p) if parts_p else np.zeros((0, 8), np.int32), n_tok))
+            if "tone" in self.capabilities and tone_list is not None and tone_list[i] is not None:   # base.py:623-624, :672-673
+                segs.append(("tone", rows1(off["tone"], _np(tone_list[i]))))
             if task == "len" and len_list is not None and len_list[i] is not None:
                 segs.append(("len", rows1(off["len"], _np(len_list[i]))))
             resp = resps_list[i] if task != "len" else None
