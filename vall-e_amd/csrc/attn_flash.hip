@@ -18,7 +18,7 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 // QB = query blocks of 16 per wave: a workgroup covers 64*QB queries; every K/V fragment read from LDS
 // feeds QB MFMAs.  K/V tiles are double-buffered in LDS: one barrier per tile.
 template <int QB>
-__global__ __launch_bounds__(256) void attn_flash_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+__global__ __launch_bounds__(256, 3) void attn_flash_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                               const int32_t* __restrict__ cu, int H, int causal) {
     constexpr int QT = 64 * QB;                               // queries per workgroup
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -54,30 +54,28 @@ __global__ __launch_bounds__(256) void attn_flash_bf16_kernel(const bf16* __rest
     }
     const float sc = 0.125f * 1.4426950408889634f;            // 1/sqrt(64) * log2(e)
 
-    uint4 kr[2], vr[2];
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-            int key = kt * 64 + row;
-            key = key < T ? key : T - 1;
-            const bf16* p = qkv + (size_t)(start + key) * ld + d + h * 64 + ch * 8;
-            kr[i] = *reinterpret_cast<const uint4*>(p);
-            vr[i] = *reinterpret_cast<const uint4*>(p + d);
-        }
-    };
-    gload(0);
+    // the next tile's K/V rows wait in four named registers (as arrays behind a lambda the compiler kept them in
+    // scratch memory, which put the global-load latency back on the critical path of every tile)
+    uint4 kr0, kr1, vr0, vr1;
+    const int lrow = tid >> 3, lch = tid & 7;                 // this thread stages rows lrow and lrow + 32, 16-byte piece lch
+    const bf16* kvbase = qkv + (size_t)start * ld + d + h * 64 + lch * 8;
+#define FA_GLOAD(KT) do { \
+        int key0 = (KT) * 64 + lrow, key1 = key0 + 32; \
+        key0 = key0 < T ? key0 : T - 1; key1 = key1 < T ? key1 : T - 1; \
+        const bf16* p0 = kvbase + (size_t)key0 * ld; const bf16* p1 = kvbase + (size_t)key1 * ld; \
+        kr0 = *reinterpret_cast<const uint4*>(p0); vr0 = *reinterpret_cast<const uint4*>(p0 + d); \
+        kr1 = *reinterpret_cast<const uint4*>(p1); vr1 = *reinterpret_cast<const uint4*>(p1 + d); \
+    } while (0)
+    FA_GLOAD(0);
     for (int kt = 0; kt < n_kt; ++kt) {
         bf16* Kb = Ks[kt & 1];
         bf16* Vb = Vs[kt & 1];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-            *reinterpret_cast<uint4*>(&Kb[row * FA_ROW + ch * 8]) = kr[i];
-            *reinterpret_cast<uint4*>(&Vb[row * FA_ROW + ch * 8]) = vr[i];
-        }
+        *reinterpret_cast<uint4*>(&Kb[lrow * FA_ROW + lch * 8]) = kr0;
+        *reinterpret_cast<uint4*>(&Vb[lrow * FA_ROW + lch * 8]) = vr0;
+        *reinterpret_cast<uint4*>(&Kb[(lrow + 32) * FA_ROW + lch * 8]) = kr1;
+        *reinterpret_cast<uint4*>(&Vb[(lrow + 32) * FA_ROW + lch * 8]) = vr1;
         __syncthreads();          // tile kt visible; the other buffer was last read in iteration kt-1, which every wave has left
-        if (kt + 1 < n_kt) gload(kt + 1);
+        if (kt + 1 < n_kt) FA_GLOAD(kt + 1);
         if (causal && kt * 64 > q_hi) continue;              // wave-uniform: this wave's queries see none of these keys
         const bool diag = causal && (kt * 64 + 63 > q_lo);   // some (query, key) pair of this wave is masked
         const bool tail = (kt + 1) * 64 > T;
@@ -172,6 +170,8 @@ __global__ __launch_bounds__(256) void attn_flash_bf16_kernel(const bf16* __rest
         }
     }
 }
+
+#undef FA_GLOAD
 
 int valle_attn_flash_bf16(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int max_T, int H, int causal,
                           hipStream_t s) {

@@ -176,7 +176,7 @@ static int dec_wave_launch(const DecWArgs& a, hipStream_t s) {
 // K-split of one 16-row tile over the waves of a workgroup.  Measured on the decode-layer chain (tools/micro_dec,
 // tools/run_dec_variants.sh, B = 16): 2 waves for K = 1024 and 8 waves for K = 4096 give 30.0 us per layer against
 // 31.8 us for (1, 4); more waves lose again to the LDS reduction; above 16 utterances K = 1024 stays on one wave
-// (B = 32: 40.1 vs 40.8 us per layer).  VALLE_DEC_NWK / VALLE_DEC_NWK_DN override (dev).
+// (B = 32: 40.1 vs 40.8 us per layer).  VALLE_DEC_NWK (1 | 2) / VALLE_DEC_NWK_DN (4 | 8) override (dev).
 static int dec_variant(int B) {
     static int v = -1;
     if (v < 0) { const char* e = getenv("VALLE_DEC_NWK"); v = e ? atoi(e) : 0; }
@@ -190,10 +190,7 @@ static int dec_variant_dn() {
 #define DEC_K1024(EPI, NORM) \
     switch (dec_variant(a.B)) { \
         case 1: return dec_wave_launch<EPI, 16, 1, NORM>(a, s); \
-        case 2: return dec_wave_launch<EPI, 8, 2, NORM>(a, s); \
-        case 4: return dec_wave_launch<EPI, 4, 4, NORM>(a, s); \
-        case 8: return dec_wave_launch<EPI, 2, 8, NORM>(a, s); \
-        default: return dec_wave_launch<EPI, 1, 16, NORM>(a, s); \
+        default: return dec_wave_launch<EPI, 8, 2, NORM>(a, s); \
     }
 
 // K = d_model in {256, 1024} for the norm-prologue linears (QKV, gate/up, head) and o_proj;
@@ -214,8 +211,7 @@ int valle_dec_wave_linear(const DecWArgs& a, int epilogue, hipStream_t s) {
         if (K == 1024) DEC_K1024(VALLE_EPI_RESID, false)
         if (K == 4096) switch (dec_variant_dn()) {
             case 4: return dec_wave_launch<VALLE_EPI_RESID, 16, 4, false>(a, s);
-            case 8: return dec_wave_launch<VALLE_EPI_RESID, 8, 8, false>(a, s);
-            default: return dec_wave_launch<VALLE_EPI_RESID, 4, 16, false>(a, s);
+            default: return dec_wave_launch<VALLE_EPI_RESID, 8, 8, false>(a, s);
         }
     }
     valle_set_error("decode linear: combination not built (K=%d norm=%d epilogue=%d)", K, a.norm, epilogue);
