@@ -11,17 +11,22 @@
 // transposing LDS read (ds_read_b64_tr_b16).
 #include "common.h"
 
+#ifndef FA_ROW
 #define FA_ROW 72   // LDS row stride in elements (144 B: 16-B aligned, shifts banks per row)
+#endif
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 // QB = query blocks of 16 per wave: a workgroup covers 64*QB queries; every K/V fragment read from LDS
-// feeds QB MFMAs.  K/V tiles are double-buffered in LDS: one barrier per tile.
+// feeds QB MFMAs.  K/V tiles are double-buffered in LDS: one barrier per tile.  Four waves per SIMD (128 VGPRs; two
+// values spill outside the loop): the softmax is a long dependent chain per tile, and residency is what hides it
+// (2 / 3 / 4 waves per SIMD: 68 / 57 / 54 us at 16 x 761 tokens).
 template <int QB>
-__global__ __launch_bounds__(256, 3) void attn_flash_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+__global__ __launch_bounds__(256, 4) void attn_flash_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                               const int32_t* __restrict__ cu, int H, int causal) {
     constexpr int QT = 64 * QB;                               // queries per workgroup
-    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // causal: the last query tiles have the most key tiles -- dispatch them first so the grid's tail is made of short ones
+    const int qt = causal ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int start = cu[b], T = cu[b + 1] - start;
     if (qt * QT >= T) return;
     const int d = H * 64, ld = 3 * d;
@@ -67,13 +72,17 @@ __global__ __launch_bounds__(256, 3) void attn_flash_bf16_kernel(const bf16* __r
         kr1 = *reinterpret_cast<const uint4*>(p1); vr1 = *reinterpret_cast<const uint4*>(p1 + d); \
     } while (0)
     FA_GLOAD(0);
+    // per-lane LDS offsets (elements) inside a tile, fixed for the whole loop: every access below is base + constant
+    const int woff = lrow * FA_ROW + lch * 8;
+    const int koff = fr * FA_ROW + fq * 8;
+    const int voff = (fq * 4 + (fr >> 2)) * FA_ROW + (fr & 3) * 4;
     for (int kt = 0; kt < n_kt; ++kt) {
         bf16* Kb = Ks[kt & 1];
         bf16* Vb = Vs[kt & 1];
-        *reinterpret_cast<uint4*>(&Kb[lrow * FA_ROW + lch * 8]) = kr0;
-        *reinterpret_cast<uint4*>(&Vb[lrow * FA_ROW + lch * 8]) = vr0;
-        *reinterpret_cast<uint4*>(&Kb[(lrow + 32) * FA_ROW + lch * 8]) = kr1;
-        *reinterpret_cast<uint4*>(&Vb[(lrow + 32) * FA_ROW + lch * 8]) = vr1;
+        *reinterpret_cast<uint4*>(Kb + woff) = kr0;
+        *reinterpret_cast<uint4*>(Vb + woff) = vr0;
+        *reinterpret_cast<uint4*>(Kb + woff + 32 * FA_ROW) = kr1;
+        *reinterpret_cast<uint4*>(Vb + woff + 32 * FA_ROW) = vr1;
         __syncthreads();          // tile kt visible; the other buffer was last read in iteration kt-1, which every wave has left
         if (kt + 1 < n_kt) FA_GLOAD(kt + 1);
         if (causal && kt * 64 > q_hi) continue;              // wave-uniform: this wave's queries see none of these keys
@@ -83,8 +92,8 @@ __global__ __launch_bounds__(256, 3) void attn_flash_bf16_kernel(const bf16* __r
         f32x4 st[QB][4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&Kb[(nt * 16 + fr) * FA_ROW + fq * 8]);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&Kb[(nt * 16 + fr) * FA_ROW + 32 + fq * 8]);
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Kb + koff + nt * 16 * FA_ROW);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Kb + koff + nt * 16 * FA_ROW + 32);
 #pragma unroll
             for (int j = 0; j < QB; ++j) {
                 st[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[j][0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -96,13 +105,15 @@ __global__ __launch_bounds__(256, 3) void attn_flash_bf16_kernel(const bf16* __r
 #pragma unroll
         for (int j = 0; j < QB; ++j) {
             if (diag || tail) {
+                // key = kt*64 + fq*4 + c with c = nt*16 + r a compile-time constant: masked <=> c > lim
+                int lim = 64;
+                if (diag) lim = q[j] - kt * 64 - fq * 4;
+                if (tail) lim = min(lim, T - 1 - kt * 64 - fq * 4);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kt * 64 + nt * 16 + fq * 4 + r;
-                        if ((tail && key >= T) || (diag && key > q[j])) st[j][nt][r] = -INFINITY;
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        if (nt * 16 + r > lim) st[j][nt][r] = -INFINITY;
             }
             float mx = fmaxf(fmaxf(st[j][0][0], st[j][0][1]), fmaxf(st[j][0][2], st[j][0][3]));
 #pragma unroll
@@ -113,16 +124,23 @@ __global__ __launch_bounds__(256, 3) void attn_flash_bf16_kernel(const bf16* __r
             const float mn = fmaxf(m[j], mx * sc);            // sc > 0: max commutes with the scale
             const float ms = (mn == -INFINITY) ? 0.f : mn;    // fully masked so far (rows past T): keep arguments finite
             const float alpha = __builtin_amdgcn_exp2f(m[j] - ms);
-            float ls = 0.f;
+            // exponent arguments and the row sum on the packed-fp32 pipe (v_pk_fma_f32 / v_pk_add_f32: two lanes of
+            // work per instruction), the exponentials themselves are quarter-rate scalars
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 sc2 = {sc, sc}, nms2 = {-ms, -ms};
+            f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(st[j][nt][r], sc, -ms));
-                    st[j][nt][r] = p;
-                    ls += p;
+                for (int r = 0; r < 4; r += 2) {
+                    f32x2 a = {st[j][nt][r], st[j][nt][r + 1]};
+                    a = __builtin_elementwise_fma(a, sc2, nms2);
+                    f32x2 p = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+                    st[j][nt][r] = p[0];
+                    st[j][nt][r + 1] = p[1];
+                    ls2 += p;
                 }
-            l[j] = l[j] * alpha + ls;
+            l[j] = l[j] * alpha + (ls2[0] + ls2[1]);
             m[j] = mn;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
@@ -137,12 +155,10 @@ __global__ __launch_bounds__(256, 3) void attn_flash_bf16_kernel(const bf16* __r
         // ---- O^T += V^T . P^T : A operand through the transposing LDS read, same key mapping
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int krow = ks * 32 + fq * 4 + (fr >> 2);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const int col = dt * 16 + (fr & 3) * 4;
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)&Vb[krow * FA_ROW + col]);
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)&Vb[(krow + 16) * FA_ROW + col]);
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Vb + voff + ks * 32 * FA_ROW + dt * 16));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Vb + voff + (ks * 32 + 16) * FA_ROW + dt * 16));
                 bf16x8 vt;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { vt[e] = lo[e]; vt[4 + e] = hi[e]; }
