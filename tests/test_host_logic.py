@@ -54,6 +54,53 @@ def test_plan_matches_oracle_embeddings_and_positions(q, timestep):
     assert plan.M == off and plan.cu[-1] == off
 
 
+def _gathered(m, plan, off, T):
+    E = table(m)
+    idx = torch.from_numpy(plan.idx[off:off + T]).long()
+    got = torch.zeros(T, m.d_model)
+    started = torch.zeros(T, dtype=torch.bool)
+    for j in range(8):
+        sel = idx[:, j] >= 0
+        got[sel] = torch.where(started[sel, None], got[sel] + E[idx[sel, j]], E[idx[sel, j]])
+        started |= sel
+    return got
+
+
+@pytest.mark.parametrize("case", ["task_prompt", "raw_text", "tone", "empty_prompt"])
+def test_plan_variants_match_oracle(case):
+    """Host planning of the wider input forms == the oracle's (which the reference goldens pin): [task, codes] prompts
+    with their position-id quirk, raw text ids, the tone token, the empty prompt of input_prompt_prefix."""
+    from vall_e_amd.models.base import RawText
+    z = load_golden("tiny_fwd")
+    phns, proms, langs = golden_inputs(z)
+    kind = "tiny_tone" if case == "tone" else "tiny"
+    m = host_model(kind)
+    o = vo.Oracle(model_cfg(kind), synth_weights(kind))
+    resps = [torch.arange(4 + i) for i in range(2)]
+    tones = None
+    if case == "task_prompt":
+        proms = [["ns", proms[0]], ["sr", proms[1]]]
+    elif case == "raw_text":
+        phns = [torch.tensor([1, 700, 33, 2]), torch.tensor([1, 4000, 2])]
+    elif case == "empty_prompt":
+        proms = [torch.zeros(0, dtype=torch.int16) for _ in range(2)]
+    elif case == "tone":
+        tones = [torch.tensor([0]), torch.tensor([0])]
+    plan = m.plan([RawText(p) for p in phns] if case == "raw_text" else phns, langs, proms, resps, 0, tone_list=tones)
+    off = 0
+    for i in range(2):
+        p = vo.plan_sequence(vo.RawText(phns[i]) if case == "raw_text" else phns[i], langs[i], proms[i], resps[i], 0,
+                             tone=None if tones is None else tones[i])
+        want = o.embed_sequence(p)
+        T = want.shape[0]
+        np.testing.assert_array_equal(_gathered(m, plan, off, T).numpy(), want.numpy())
+        np.testing.assert_array_equal(plan.pos[off:off + T], p.pos.numpy())
+        off += T
+    assert plan.M == off
+    if case == "task_prompt":
+        assert plan.pos[plan.lens[0] - 1] == 1                  # the tail the reference fills with 1 (base.py:988-990)
+
+
 def test_null_cfg_plan_has_no_prompt():
     m = host_model()
     plan = m.plan([torch.tensor([1, 2])], [torch.tensor([0])], None, [torch.arange(9)], 0)
