@@ -147,6 +147,8 @@ def main():
         out = torch.stack([f.to(torch.int16) for f in full])            # (B, R, 8)
         if dist is not None:
             raw = out.view(torch.uint8)                                 # RCCL has no int16: ship the bytes
+            if dist.get_backend() == "gloo":                            # the CPU rehearsal backend gathers host tensors
+                raw = raw.cpu()
             gathered = [torch.empty_like(raw) for _ in range(world)]
             dist.all_gather(gathered, raw)                              # RCCL: codes of every rank
             assert all(g.shape == raw.shape for g in gathered)
