@@ -114,15 +114,24 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnDecArgs a
     }
     __syncthreads();
     if (threadIdx.x < 64) {
-        float mm = sm_m[0];
+        // cross-wave merge by wave 0: lane w < NW owns wave w's rescale factor (one exponential per lane instead of NW
+        // dependent ones per lane), broadcast by readlane; every LDS operand is requested before the first use
+        const int lw = threadIdx.x < NW ? threadIdx.x : NW - 1;
+        const float mw = sm_m[lw], lw_l = sm_l[lw];
+        float ov[NW];
 #pragma unroll
-        for (int w = 1; w < NW; ++w) mm = fmaxf(mm, sm_m[w]);
+        for (int w = 0; w < NW; ++w) ov[w] = sm_o[w][threadIdx.x];
+        float mm = mw;
+#pragma unroll
+        for (int o = NW >> 1; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));   // lanes >= NW mirror lane NW-1: harmless
+        mm = __shfl(mm, 0, 64);
+        const float scl = (mw == -INFINITY) ? 0.f : expf(mw - mm);
         float num = 0.f, den = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            const float sc = (sm_m[w] == -INFINITY) ? 0.f : expf(sm_m[w] - mm);
-            num += sm_o[w][threadIdx.x] * sc;
-            den += sm_l[w] * sc;
+            const float sc = __shfl(scl, w, 64);
+            num += ov[w] * sc;
+            den += __shfl(lw_l, w, 64) * sc;
         }
         const int col = h * 64 + threadIdx.x;
         const size_t off = a.out_frag ? (size_t)(b >> 4) * 16 * a.H * 64 + (size_t)(((((col >> 5) << 6) + (((col >> 3) & 3) << 4) + (b & 15)) << 3) + (col & 7))
