@@ -81,6 +81,7 @@ int main() {
         char b[96];
         snprintf(b, sizeof b, "%s  1 stream eager", nm[which]); run(b, 1, which, true, false);
         snprintf(b, sizeof b, "%s  1 stream graph", nm[which]); run(b, 1, which, true, true);
+        snprintf(b, sizeof b, "%s  2 streams eager, distinct buffers", nm[which]); run(b, 2, which, false, false);
         snprintf(b, sizeof b, "%s  2 branches graph, same buffers", nm[which]); run(b, 2, which, true, true);
         snprintf(b, sizeof b, "%s  2 branches graph, distinct buffers", nm[which]); run(b, 2, which, false, true);
         snprintf(b, sizeof b, "%s  4 branches graph, same buffers", nm[which]); run(b, 4, which, true, true);
