@@ -69,12 +69,12 @@ class AR_NAR(Base):
                 len_list=None, text_list=None, training=None, disable_tqdm=False, use_lora=None, **sampling_kwargs):
         # tone tokens enter a sequence only with the "tone" capability (base.py:623-624); every pass the reference plans
         # for this call -- conditional, null, len -- carries the same list, so it is kept for the duration of the call
-        self._call_tones = tone_list if "tone" in self.capabilities else None
+        self._call_state.tones = tone_list if "tone" in self.capabilities else None
         try:
             return self._forward(task_list, phns_list, proms_list, resps_list, lang_list, len_list, text_list, training,
                                  **sampling_kwargs)
         finally:
-            self._call_tones = None
+            self._call_state.tones = None
 
     def _forward(self, task_list, phns_list, proms_list, resps_list, lang_list, len_list, text_list, training, **sampling_kwargs):
         if text_list is not None and phns_list is None:                       # raw text in place of phonemes (base.py:609-610):
@@ -269,7 +269,7 @@ class AR_NAR(Base):
                                        step=step, bump_ctx=step > 0)
                 if bool(stopped.all().item()):
                     break
-        torch.cuda.synchronize(dev)
+        torch.cuda.current_stream(dev).synchronize()      # this call's stream only: another stream may be busy with other work
         seq_h, len_h = seq.cpu().numpy(), seq_len.cpu().numpy()
         out = []
         for i in range(B):

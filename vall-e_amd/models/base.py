@@ -10,6 +10,8 @@ from __future__ import annotations
 import ctypes as C
 from collections import namedtuple
 
+import threading
+
 import numpy as np
 import torch
 
@@ -104,6 +106,7 @@ class Base:
         self._handle = None
         self._bufs = {}
         self._ws = None
+        self._call_state = threading.local()       # per-thread state of the call in flight (tone list)
         self._keep = []
 
     # ------------------------------------------------------------- nn.Module-ish surface
@@ -321,7 +324,7 @@ class Base:
         B = len(resps_list)
         q = quant_level
         if tone_list is None:                         # the call's tone list (AR_NAR.forward keeps it for every pass it plans)
-            tone_list = getattr(self, "_call_tones", None)
+            tone_list = getattr(self._call_state, "tones", None)
         idx_all, pos_all, lens, out_len = [], [], [], []
         sep_row = np.full((1, 8), -1, dtype=np.int32)
         sep_row[0, 0] = off["sep"]
@@ -408,20 +411,35 @@ class Base:
 
     # ------------------------------------------------------------------------ dense forward
     def _workspace(self, nbytes):
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = None
-            self._ws = torch.empty(_round_up(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
-        return self._ws
+        # one workspace per stream: work enqueued on two streams must not share scratch memory
+        if self._ws is None:
+            self._ws = {}
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            self._ws.pop(key, None)
+            ws = self._ws[key] = torch.empty(_round_up(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
+        return ws
 
     def _i32(self, arr):
-        return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)).to(self.device, non_blocking=True)
+        return self._h2d(np.ascontiguousarray(arr, dtype=np.int32))
+
+    def _h2d(self, arr):
+        """Asynchronous host->device copy of a numpy array through PINNED staging memory.  An asynchronous copy straight
+        from a pageable numpy buffer may still be reading it after this returns, while the buffer is already freed and
+        reused by the host (seen as wrong codes of one utterance once a second host thread was allocating concurrently);
+        torch's pinned allocator keeps a staging block alive until the copy that uses it has completed."""
+        t = torch.from_numpy(arr)
+        if self.device.type != "cuda":
+            return t.to(self.device)
+        return t.pin_memory().to(self.device, non_blocking=True)
 
     def _upload_i32(self, *arrays):
         """Several integer host arrays -> device int32 views of ONE uploaded buffer (one copy, one sync)."""
         flat = [np.ascontiguousarray(a, dtype=np.int32).reshape(-1) for a in arrays]
         pad = [(-len(f)) % 4 for f in flat]                                   # keep every view 16-byte aligned
         buf = np.concatenate([np.concatenate((f, np.zeros(p, np.int32))) for f, p in zip(flat, pad)]) if flat else np.zeros(0, np.int32)
-        dev = torch.from_numpy(buf).to(self.device, non_blocking=True)
+        dev = self._h2d(buf)
         out, o = [], 0
         for a, f, p in zip(arrays, flat, pad):
             out.append(dev[o:o + len(f)].view(np.asarray(a).shape))
