@@ -97,10 +97,12 @@ def get_ref_model(kind, dtype=torch.float32, **synth_kw):
     if key in _models:
         return _models[key]
     mcfg = {"full": vcfg.repo_default_model, "tiny": vcfg.tiny_model, "tiny_len": vcfg.tiny_len_model,
-            "tiny_nc": vcfg.tiny_nc_model, "tiny_tone": vcfg.tiny_tone_model}[kind]()
+            "tiny_nc": vcfg.tiny_nc_model, "tiny_tone": vcfg.tiny_tone_model, "tiny_upi": vcfg.tiny_upi_model}[kind]()
     model = rh.build_reference_model(size=mcfg.size, capabilities=list(mcfg.capabilities),
-                                     noncausal_masks=mcfg.experimental.noncausal_masks)
+                                     noncausal_masks=mcfg.experimental.noncausal_masks,
+                                     unified_position_ids=mcfg.experimental.unified_position_ids)
     assert model.noncausal_masks == mcfg.experimental.noncausal_masks
+    assert model.unified_position_ids == mcfg.experimental.unified_position_ids
     synth_kw = dict(synth_kw)
     sd = synth_state_dict(mcfg, synth_kw.pop("weight_seed", WEIGHT_SEED), **synth_kw)
     missing = model.load_state_dict(sd, strict=True)
@@ -675,6 +677,15 @@ def scen_tiny_tone():
     save("tiny_tone", **d)
 
 
+def scen_tiny_unified_positions():
+    """``unified_position_ids=True`` (the reference's dataclass default, config.py:292; data/config.yaml switches it off):
+    no per-segment ids, the stack sees HF's arange over the whole (right-padded) batch (arch/llama.py:825-831).  AR with
+    and without guidance, rolling prefix, NAR levels."""
+    mk = lambda s: synth_batch(s, 3, n_phn=12, n_prom=20, ragged=True)
+    ar_nar_scenario("tiny_upi_ar_nar", "tiny_upi", mk, 171, steps=14)
+    ar_nar_scenario("tiny_upi_cfg", "tiny_upi", mk, 181, steps=9, ar_kw=dict(cfg_strength=2.5), nar=False)
+
+
 def scen_full_b1():
     ref = rh.load_reference()
     phns, proms, langs = qnt_inputs()
@@ -732,6 +743,7 @@ SCENARIOS = {
     "tiny_task_prompt": scen_tiny_task_prompt,
     "tiny_raw_text": scen_tiny_raw_text,
     "tiny_tone": scen_tiny_tone,
+    "tiny_unified_positions": scen_tiny_unified_positions,
     "full_b1": scen_full_b1,
     "full_b3": scen_full_b3,
     "full_narlen": scen_full_narlen,

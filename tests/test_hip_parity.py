@@ -498,6 +498,13 @@ def test_tiny_tone_inputs(gpu_device):
         np.testing.assert_array_equal(c0[b].cpu().numpy(), z0[f"ar_codes_{b}"])
 
 
+def test_tiny_unified_position_ids(gpu_device):
+    """unified_position_ids=True: the KV-cache decode continues the arange of the prefill (response token n sits at
+    rows-before-the-response + n, which differs between the conditional and the null pass of the guidance)."""
+    _ar_nar("tiny_upi", "tiny_upi_ar_nar")
+    _ar_nar("tiny_upi", "tiny_upi_cfg")
+
+
 def test_edge_shapes_match_oracle(gpu_device):
     """Smallest and most ragged shapes: no prompt, one-phoneme text, one AR step, one-frame NAR, batch of one."""
     m, o = hip_model("tiny"), oracle("tiny")

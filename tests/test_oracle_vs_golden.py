@@ -344,6 +344,13 @@ def test_tiny_tone_inputs():
     assert any((plain[b].numpy() != z[f"ar_codes_{b}"]).any() for b in range(B))
 
 
+def test_tiny_unified_position_ids():
+    """unified_position_ids=True (reference dataclass default, config.py:292): one arange over the sequence."""
+    _ar_nar("tiny_upi", "tiny_upi_ar_nar")
+    _ar_nar("tiny_upi", "tiny_upi_ar_nar", use_cache=True)
+    _ar_nar("tiny_upi", "tiny_upi_cfg")
+
+
 def test_full_b1_configs0():
     """BASELINE.json configs[0]: repo-default model, data/qnt.enc prompt, greedy AR + NAR."""
     _ar_nar("full", "full_b1")

@@ -150,6 +150,14 @@ def tiny_tone_model(**kw) -> Model:
     return m
 
 
+def tiny_upi_model(**kw) -> Model:
+    """``tiny_model`` with ``unified_position_ids`` (the reference's dataclass default, config.py:292): one arange over
+    the whole sequence instead of per-segment position ids."""
+    m = tiny_model(**kw)
+    m.experimental.unified_position_ids = True
+    return m
+
+
 def tiny_nc_model(**kw) -> Model:
     """Tiny sibling of the published ``ar+nar-len-llama-8`` switches: ``len`` head and ``noncausal_masks``
     (NAR levels attend in both directions, base.py:1230-1233)."""

@@ -186,7 +186,6 @@ class AR_NAR(Base):
         seq_len = self._i32([len(p) for p in prefix])
         stopped = torch.zeros(B, dtype=torch.int32, device=dev)
         scores = torch.zeros(B, dtype=torch.float32, device=dev)
-        resp_pos0 = torch.zeros(B, dtype=torch.int32, device=dev)
         slot = torch.arange(B, dtype=torch.int32, device=dev)
 
         states, first_logits = [], []
@@ -202,10 +201,14 @@ class AR_NAR(Base):
             pos0 = torch.zeros(B, dtype=torch.int32, device=dev)
             lg = self.forward_dense(plan, rows, cache=(kc, vc, cache_T, stride, slot, pos0))
             ctx_len = self._i32(plan.lens)
+            # RoPE position of response token 0: per-segment position ids restart at 0 (base.py:984); with
+            # unified_position_ids (HF default arange over the whole sequence, arch/llama.py:825-831) it is the number of
+            # rows in front of the response segment -- which differs between the conditional and the null pass
+            resp_pos0 = self._i32([plan.lens[i] - len(prefix[i]) if self.unified_position_ids else 0 for i in range(B)])
             st = L.ARState(B, cap, seq.data_ptr(), seq_len.data_ptr(), ctx_len.data_ptr(), resp_pos0.data_ptr(),
                            slot.data_ptr(), stopped.data_ptr(), scores.data_ptr(), kc.data_ptr(), vc.data_ptr(),
                            cache_T, stride, self._off["resp0"], 0, V)
-            states.append((st, (kc, vc, ctx_len)))
+            states.append((st, (kc, vc, ctx_len, resp_pos0)))
             first_logits.append(lg)
         ws_bytes = lib.valle_decode_workspace_bytes(self._handle, B)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
