@@ -97,10 +97,11 @@ def get_ref_model(kind, dtype=torch.float32, **synth_kw):
     if key in _models:
         return _models[key]
     mcfg = {"full": vcfg.repo_default_model, "tiny": vcfg.tiny_model, "tiny_len": vcfg.tiny_len_model,
-            "tiny_nc": vcfg.tiny_nc_model, "tiny_tone": vcfg.tiny_tone_model, "tiny_upi": vcfg.tiny_upi_model}[kind]()
+            "tiny_nc": vcfg.tiny_nc_model, "tiny_tone": vcfg.tiny_tone_model, "tiny_upi": vcfg.tiny_upi_model, "tiny_nobias": vcfg.tiny_nobias_model}[kind]()
     model = rh.build_reference_model(size=mcfg.size, capabilities=list(mcfg.capabilities),
                                      noncausal_masks=mcfg.experimental.noncausal_masks,
-                                     unified_position_ids=mcfg.experimental.unified_position_ids)
+                                     unified_position_ids=mcfg.experimental.unified_position_ids,
+                                     classifiers_bias=mcfg.experimental.classifiers_bias)
     assert model.noncausal_masks == mcfg.experimental.noncausal_masks
     assert model.unified_position_ids == mcfg.experimental.unified_position_ids
     synth_kw = dict(synth_kw)
@@ -684,6 +685,8 @@ def scen_tiny_unified_positions():
     mk = lambda s: synth_batch(s, 3, n_phn=12, n_prom=20, ragged=True)
     ar_nar_scenario("tiny_upi_ar_nar", "tiny_upi", mk, 171, steps=14)
     ar_nar_scenario("tiny_upi_cfg", "tiny_upi", mk, 181, steps=9, ar_kw=dict(cfg_strength=2.5), nar=False)
+    # classifiers_bias=False: heads without a bias vector
+    ar_nar_scenario("tiny_nobias_ar_nar", "tiny_nobias", mk, 191, steps=10)
 
 
 def scen_full_b1():

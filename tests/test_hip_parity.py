@@ -505,6 +505,18 @@ def test_tiny_unified_position_ids(gpu_device):
     _ar_nar("tiny_upi", "tiny_upi_cfg")
 
 
+def test_tiny_classifiers_without_bias(gpu_device):
+    """classifiers_bias=False: no bias vector in the state dict, the head kernels run without one (fp32 and bf16)."""
+    _ar_nar("tiny_nobias", "tiny_nobias_ar_nar")
+    from vall_e_amd.synth import synth_batch
+    phns, proms, langs = synth_batch(5, 3, n_phn=10, n_prom=12, ragged=True)
+    m = hip_model("tiny_nobias", torch.bfloat16)
+    assert not any(k.endswith(".bias") for k in m.state_dict_spec())
+    codes = m(task_list=["tts"] * 3, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=9, temperature=0.0)
+    full = m(task_list=["tts"] * 3, phns_list=phns, proms_list=proms, lang_list=langs, resps_list=codes, temperature=0.0)
+    assert all(f.shape == (9, 8) for f in full)
+
+
 def test_edge_shapes_match_oracle(gpu_device):
     """Smallest and most ragged shapes: no prompt, one-phoneme text, one AR step, one-frame NAR, batch of one."""
     m, o = hip_model("tiny"), oracle("tiny")

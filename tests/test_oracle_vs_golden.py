@@ -351,6 +351,10 @@ def test_tiny_unified_position_ids():
     _ar_nar("tiny_upi", "tiny_upi_cfg")
 
 
+def test_tiny_classifiers_without_bias():
+    _ar_nar("tiny_nobias", "tiny_nobias_ar_nar")
+
+
 def test_full_b1_configs0():
     """BASELINE.json configs[0]: repo-default model, data/qnt.enc prompt, greedy AR + NAR."""
     _ar_nar("full", "full_b1")

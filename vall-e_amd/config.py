@@ -158,6 +158,13 @@ def tiny_upi_model(**kw) -> Model:
     return m
 
 
+def tiny_nobias_model(**kw) -> Model:
+    """``tiny_model`` with ``classifiers_bias=False``: heads without a bias vector (base.py:179-199)."""
+    m = tiny_model(**kw)
+    m.experimental.classifiers_bias = False
+    return m
+
+
 def tiny_nc_model(**kw) -> Model:
     """Tiny sibling of the published ``ar+nar-len-llama-8`` switches: ``len`` head and ``noncausal_masks``
     (NAR levels attend in both directions, base.py:1230-1233)."""
