@@ -97,7 +97,7 @@ def get_ref_model(kind, dtype=torch.float32, **synth_kw):
     if key in _models:
         return _models[key]
     mcfg = {"full": vcfg.repo_default_model, "tiny": vcfg.tiny_model, "tiny_len": vcfg.tiny_len_model,
-            "tiny_nc": vcfg.tiny_nc_model, "tiny_tone": vcfg.tiny_tone_model, "tiny_upi": vcfg.tiny_upi_model, "tiny_nobias": vcfg.tiny_nobias_model}[kind]()
+            "tiny_nc": vcfg.tiny_nc_model, "tiny_tone": vcfg.tiny_tone_model, "tiny_upi": vcfg.tiny_upi_model, "tiny_nobias": vcfg.tiny_nobias_model, "tiny_nc_upi": vcfg.tiny_nc_upi_model}[kind]()
     model = rh.build_reference_model(size=mcfg.size, capabilities=list(mcfg.capabilities),
                                      noncausal_masks=mcfg.experimental.noncausal_masks,
                                      unified_position_ids=mcfg.experimental.unified_position_ids,
@@ -685,6 +685,9 @@ def scen_tiny_unified_positions():
     mk = lambda s: synth_batch(s, 3, n_phn=12, n_prom=20, ragged=True)
     ar_nar_scenario("tiny_upi_ar_nar", "tiny_upi", mk, 171, steps=14)
     ar_nar_scenario("tiny_upi_cfg", "tiny_upi", mk, 181, steps=9, ar_kw=dict(cfg_strength=2.5), nar=False)
+    # the switches of a checkpoint that names only noncausal_masks and the len capability: unified ids + two-way NAR masks
+    phns, proms, langs = synth_batch(201, 2, n_phn=10, n_prom=16, ragged=True)
+    narlen_scenario("tiny_nc_upi_narlen", "tiny_nc_upi", phns, proms, langs, lens=[15, 21], max_steps=5)
     # classifiers_bias=False: heads without a bias vector
     ar_nar_scenario("tiny_nobias_ar_nar", "tiny_nobias", mk, 191, steps=10)
 

@@ -503,6 +503,7 @@ def test_tiny_unified_position_ids(gpu_device):
     rows-before-the-response + n, which differs between the conditional and the null pass of the guidance)."""
     _ar_nar("tiny_upi", "tiny_upi_ar_nar")
     _ar_nar("tiny_upi", "tiny_upi_cfg")
+    _narlen("tiny_nc_upi", "tiny_nc_upi_narlen")     # + noncausal NAR masks + len capability, through NAR-len and the levels
 
 
 def test_tiny_classifiers_without_bias(gpu_device):

@@ -174,8 +174,8 @@ def _narlen(kind, name, **kw):
     o = make_oracle(kind)
     if "level0_first_step_logits_0" in z:
         n0 = int(z["lens"][0])
-        plans = [vo.plan_sequence(phns[i], langs[i], proms[i], torch.full((int(z["lens"][i]),), o.mask_token), 0, timestep=True)
-                 for i in range(len(phns))]
+        plans = [vo.plan_sequence(phns[i], langs[i], proms[i], torch.full((int(z["lens"][i]),), o.mask_token), 0, timestep=True,
+                                  unified_pos=o.unified_pos) for i in range(len(phns))]
         assert_close(o.forward(plans, rows=[int(x) for x in z["lens"]])[0], z["level0_first_step_logits_0"][-n0:], 5e-4, 5e-4)
     full = o.nar_len(phns, proms, langs, [int(x) for x in z["lens"]], max_steps=int(z["max_steps"]), temperature=0.0, **kw)
     for b in range(len(phns)):
@@ -349,6 +349,7 @@ def test_tiny_unified_position_ids():
     _ar_nar("tiny_upi", "tiny_upi_ar_nar")
     _ar_nar("tiny_upi", "tiny_upi_ar_nar", use_cache=True)
     _ar_nar("tiny_upi", "tiny_upi_cfg")
+    _narlen("tiny_nc_upi", "tiny_nc_upi_narlen")     # + noncausal NAR masks + len capability, through NAR-len and the levels
 
 
 def test_tiny_classifiers_without_bias():

@@ -173,6 +173,14 @@ def tiny_nc_model(**kw) -> Model:
     return m
 
 
+def tiny_nc_upi_model(**kw) -> Model:
+    """``tiny_nc_model`` with the reference's dataclass default ``unified_position_ids=True``: every switch of a
+    checkpoint whose config names only ``noncausal_masks`` and the ``len`` capability."""
+    m = tiny_nc_model(**kw)
+    m.experimental.unified_position_ids = True
+    return m
+
+
 @dataclass
 class Inference:
     # vall_e/config.py:849-862
