@@ -605,6 +605,7 @@ def scen_tiny_task_prompt():
     d["prompt_tasks"] = np.array(tasks)
     d.update(pack_list("ar_codes", codes)), d.update(pack_list("nar_codes", full))
     d["first_logits"] = torch.stack(rec.calls[0]["logits"])
+    d["ar_step_logits"] = torch.stack([torch.stack(c["logits"]) for c in rec.calls[:n_ar]])   # last row of every AR step
     d["pos_ids_0"] = pos0
     d["steps"], d["min_gap"] = np.int64(10), np.float64(gap)
     save("tiny_task_prompt", **d)

@@ -438,7 +438,9 @@ def test_tiny_task_token_prompt(gpu_device):
     m = hip_model("tiny")
     codes, logits = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=int(z["steps"]),
                       temperature=0.0, return_logits=True)
-    torch.testing.assert_close(logits[0].cpu(), torch.from_numpy(z["first_logits"]), rtol=1e-3, atol=1e-3)
+    # every step's logits: with a task token the position ids of old tokens move from step to step, and the HIP path
+    # recomputes the sequence instead of using its KV cache (a cache is off by ~1e-2 here)
+    torch.testing.assert_close(torch.stack([l.cpu() for l in logits]), torch.from_numpy(z["ar_step_logits"]), rtol=2e-4, atol=2e-4)
     for b in range(B):
         np.testing.assert_array_equal(codes[b].cpu().numpy(), z[f"ar_codes_{b}"])
     full = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, resps_list=[c.clone() for c in codes],

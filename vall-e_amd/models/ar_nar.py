@@ -188,6 +188,17 @@ class AR_NAR(Base):
         scores = torch.zeros(B, dtype=torch.float32, device=dev)
         slot = torch.arange(B, dtype=torch.int32, device=dev)
 
+        # A [task, codes] prompt makes the reference's position ids one short per task token (base.py:964-990): every row
+        # behind the prompt reads its neighbour's id and the LAST row -- the newest token -- always gets 1, so a token's
+        # position changes from one step to the next.  A KV cache holds keys rotated once; these calls therefore recompute
+        # the sequence every step, as the reference does (measured: cache-path logits off by 1e-2 on the tiny model).
+        if not self.unified_position_ids and proms_list is not None and any(
+                isinstance(p, (list, tuple)) and any(isinstance(x, str) for x in p) for p in proms_list):
+            all_logits = self._ar_recompute(passes, lang_list, prefix, n_steps, seq, seq_len, stopped, scores, sp, cap,
+                                            cfg_strength, cfg_rescale, return_logits)
+            return self._ar_finish(seq, seq_len, prefix, prefix_lens, prefix_context, start_slice, refine_on_stop, n_steps,
+                                   phns_list, lang_list, proms_list, return_logits, all_logits)
+
         states, first_logits = [], []
         for phns, proms in passes:
             plan = self.plan(phns, lang_list, proms, [torch.from_numpy(p) for p in prefix], 0)
@@ -272,6 +283,13 @@ class AR_NAR(Base):
                                        step=step, bump_ctx=step > 0)
                 if bool(stopped.all().item()):
                     break
+        return self._ar_finish(seq, seq_len, prefix, prefix_lens, prefix_context, start_slice, refine_on_stop, n_steps,
+                               phns_list, lang_list, proms_list, return_logits, all_logits)
+
+    def _ar_finish(self, seq, seq_len, prefix, prefix_lens, prefix_context, start_slice, refine_on_stop, n_steps,
+                   phns_list, lang_list, proms_list, return_logits, all_logits):
+        """Host side of the loop's end (ar_nar.py:863-890): prune at the stop token, cut prefixes, optional refine."""
+        dev, B = self.device, seq.shape[0]
         torch.cuda.current_stream(dev).synchronize()      # this call's stream only: another stream may be busy with other work
         seq_h, len_h = seq.cpu().numpy(), seq_len.cpu().numpy()
         out = []
@@ -292,6 +310,34 @@ class AR_NAR(Base):
         if return_logits:
             return out, all_logits
         return out
+
+    def _ar_recompute(self, passes, lang_list, prefix, n_steps, seq, seq_len, stopped, scores, sp, cap, cfg_strength,
+                      cfg_rescale, return_logits):
+        """The AR loop without a KV cache: one dense pass over the whole sequence per step (and per guidance pass), the
+        reference's own schedule (base.py:521).  Only for inputs whose position ids move between steps."""
+        B = seq.shape[0]
+        V = self.cls_tokens[0]
+        all_logits = []
+        for step in range(n_steps):
+            len_h = seq_len.cpu().numpy()
+            seq_h = seq.cpu().numpy()
+            resp_in = [seq_h[i, : len_h[i]].astype(np.int64) for i in range(B)]
+            counts = [int(n) + 1 for n in len_h] if cfg_strength > 0 else [1] * B
+            outs = []
+            for phns, proms in passes:
+                plan = self.plan(phns, lang_list, proms, resp_in, 0)
+                rows, off = self.tail_rows(plan, counts)
+                outs.append(self.forward_dense(plan, rows))
+            logits = outs[0]
+            if cfg_strength > 0:
+                self.cfg_combine(outs[0], outs[1], V, off, cfg_strength, cfg_rescale)
+                logits = outs[0].index_select(0, torch.from_numpy(off[1:].astype(np.int64) - 1).to(self.device)).contiguous()
+            if return_logits:
+                all_logits.append(logits[:, :V].clone())
+            self._ar_sample_append(logits, V, seq, seq_len, [], stopped, scores, sp, cap, step=step)
+            if bool(stopped.all().item()):
+                break
+        return all_logits
 
     def _refine_on_stop(self, out, seq_h, len_h, n_prefix, n_steps, phns_list, lang_list, proms_list):
         """ar_nar.py:874-883: the reference re-reads the logits of its LAST iteration greedily -- for every utterance
