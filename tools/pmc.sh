@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh TAG -- HBM traffic counters of the decode layer chain (tools/micro_dec, eager), one counter per pass
+# usage: tools/pmc.sh TAG -- HBM traffic counters of the decode layer chain (tools/micro_dec, eager), one counter per pass
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for C in FETCH_SIZE WRITE_SIZE; do

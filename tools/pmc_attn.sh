@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc_attn.sh TAG -- SQ counters of the dense-pass attention kernel (tools/time_attn.py), one pass per counter set
+# usage: tools/pmc_attn.sh TAG -- SQ counters of the dense-pass attention kernel (tools/time_attn.py), one pass per counter set
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 python3 $R/tools/time_attn.py || exit 1

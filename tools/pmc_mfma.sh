@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc_mfma.sh TAG -- MFMA counters of the dense-pass GEMMs (tools/micro_gemm: the four GEMMs of one NAR layer, M = 12,176)
+# usage: tools/pmc_mfma.sh TAG -- MFMA counters of the dense-pass GEMMs (tools/micro_gemm: the four GEMMs of one NAR layer, M = 12,176)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 export LD_LIBRARY_PATH=$R/vall-e_amd:$LD_LIBRARY_PATH

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof.sh TAG  -- kernel-trace profile of one bench step; summary -> gpurun_out/prof_TAG
+# usage: tools/prof.sh TAG  -- kernel-trace profile of one bench step; summary -> gpurun_out/prof_TAG
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$1 -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_$1.log 2>&1

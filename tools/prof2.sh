@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof2.sh TAG WHICH -- kernel-trace profile of tools/time_configs.py WHICH (narlen | longform)
+# usage: tools/prof2.sh TAG WHICH -- kernel-trace profile of tools/time_configs.py WHICH (narlen | longform)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof2_$1 -- python $R/tools/time_configs.py $2 > $R/gpurun_out/prof2_$1.log 2>&1

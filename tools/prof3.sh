@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof3.sh TAG -- kernel-trace of one bench step + idle-gap analysis (tools/timeline.py)
+# usage: tools/prof3.sh TAG -- kernel-trace of one bench step + idle-gap analysis (tools/timeline.py)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$1 -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_$1.log 2>&1 || exit 1
