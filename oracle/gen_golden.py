@@ -595,6 +595,9 @@ def scen_tiny_task_prompt():
             x = model.inputs_to_embeddings(inputs, [0, 0])
             m = torch.ones((1, x[0].shape[0]))
             pos0 = model.inputs_to_position_ids(inputs[:1], m)[0]
+        with torch.inference_mode():                  # guidance on top: the null pass has no prompt, hence no task token
+            cfg_codes = model(task_list=["tts"] * 2, phns_list=[p.clone() for p in phns], proms_list=mk(), lang_list=[l.clone() for l in langs],
+                              disable_tqdm=True, max_duration=10, temperature=0.0, cfg_strength=3.0)
         gap = min(top2_gap(r) for c in rec.calls[:n_ar] for r in c["logits"])
         print(f"  [tiny_task_prompt] seed {seed} AR min top-2 gap {gap:.3e}")
         if gap > MIN_GAP:
@@ -603,7 +606,7 @@ def scen_tiny_task_prompt():
         raise RuntimeError("tiny_task_prompt: no seed with a usable margin")
     d = input_arrays(phns, proms, langs)
     d["prompt_tasks"] = np.array(tasks)
-    d.update(pack_list("ar_codes", codes)), d.update(pack_list("nar_codes", full))
+    d.update(pack_list("ar_codes", codes)), d.update(pack_list("nar_codes", full)), d.update(pack_list("ar_cfg_codes", cfg_codes))
     d["first_logits"] = torch.stack(rec.calls[0]["logits"])
     d["ar_step_logits"] = torch.stack([torch.stack(c["logits"]) for c in rec.calls[:n_ar]])   # last row of every AR step
     d["pos_ids_0"] = pos0

@@ -443,6 +443,10 @@ def test_tiny_task_token_prompt(gpu_device):
     torch.testing.assert_close(torch.stack([l.cpu() for l in logits]), torch.from_numpy(z["ar_step_logits"]), rtol=2e-4, atol=2e-4)
     for b in range(B):
         np.testing.assert_array_equal(codes[b].cpu().numpy(), z[f"ar_codes_{b}"])
+    guided = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=int(z["steps"]),
+               temperature=0.0, cfg_strength=3.0)
+    for b in range(B):
+        np.testing.assert_array_equal(guided[b].cpu().numpy(), z[f"ar_cfg_codes_{b}"])
     full = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, resps_list=[c.clone() for c in codes],
              temperature=0.0)
     for b in range(B):
