@@ -193,22 +193,28 @@ static int dec_variant_dn() {
         default: return dec_wave_launch<EPI, 8, 2, NORM>(a, s); \
     }
 
-// K = d_model in {256, 1024} for the norm-prologue linears (QKV, gate/up, head) and o_proj;
-// down_proj K = d_ff in {1024, 4096}.
+// K = d_model in {256, 512, 768, 1024} (the reference's "quarter", "half", 0.75 and "full" sizes, config.py:462-469) for
+// the norm-prologue linears (QKV, gate/up, head) and o_proj; down_proj K = d_ff = 4 d_model.  Only the full size is tuned.
+#define DEC_KSMALL(EPI, NORM) \
+    if (K == 256) return dec_wave_launch<EPI, 4, 1, NORM>(a, s); \
+    if (K == 512) return dec_wave_launch<EPI, 8, 1, NORM>(a, s); \
+    if (K == 768) return dec_wave_launch<EPI, 12, 1, NORM>(a, s);
 int valle_dec_wave_linear(const DecWArgs& a, int epilogue, hipStream_t s) {
     VALLE_REQUIRE(a.B >= 1 && a.B <= 32, VALLE_E_UNSUPPORTED, "wave-streaming decode linears take 1..32 utterances, got %d", a.B);
     VALLE_REQUIRE(a.x && a.W && a.out, VALLE_E_ARG, "decode linear: null pointer");
     const int K = a.K;
     if (a.norm) {
         switch (epilogue) {
-            case VALLE_EPI_GEGLU:  if (K == 256) return dec_wave_launch<VALLE_EPI_GEGLU, 4, 1, true>(a, s);  if (K == 1024) DEC_K1024(VALLE_EPI_GEGLU, true) break;
-            case VALLE_EPI_F32OUT: if (K == 256) return dec_wave_launch<VALLE_EPI_F32OUT, 4, 1, true>(a, s); if (K == 1024) DEC_K1024(VALLE_EPI_F32OUT, true) break;
-            case DEC_EPI_QKV:      if (K == 256) return dec_wave_launch<DEC_EPI_QKV, 4, 1, true>(a, s);      if (K == 1024) DEC_K1024(DEC_EPI_QKV, true) break;
+            case VALLE_EPI_GEGLU: DEC_KSMALL(VALLE_EPI_GEGLU, true) if (K == 1024) DEC_K1024(VALLE_EPI_GEGLU, true) break;
+            case VALLE_EPI_F32OUT: DEC_KSMALL(VALLE_EPI_F32OUT, true) if (K == 1024) DEC_K1024(VALLE_EPI_F32OUT, true) break;
+            case DEC_EPI_QKV: DEC_KSMALL(DEC_EPI_QKV, true) if (K == 1024) DEC_K1024(DEC_EPI_QKV, true) break;
         }
     } else if (epilogue == VALLE_EPI_RESID) {
         VALLE_REQUIRE(a.resid != nullptr, VALLE_E_ARG, "decode linear: residual missing");
-        if (K == 256) return dec_wave_launch<VALLE_EPI_RESID, 4, 1, false>(a, s);
+        DEC_KSMALL(VALLE_EPI_RESID, false)
         if (K == 1024) DEC_K1024(VALLE_EPI_RESID, false)
+        if (K == 2048) return dec_wave_launch<VALLE_EPI_RESID, 8, 4, false>(a, s);
+        if (K == 3072) return dec_wave_launch<VALLE_EPI_RESID, 12, 4, false>(a, s);
         if (K == 4096) switch (dec_variant_dn()) {
             case 4: return dec_wave_launch<VALLE_EPI_RESID, 16, 4, false>(a, s);
             default: return dec_wave_launch<VALLE_EPI_RESID, 8, 8, false>(a, s);

@@ -226,7 +226,7 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
     VALLE_REQUIRE(ws.ok, VALLE_E_WORKSPACE, "valle_ar_decode: workspace %zu B too small (need %zu)", workspace_bytes,
                   valle_decode_workspace_bytes(m, B));
     hipStream_t s = (hipStream_t)stream;
-    const bool wavepath = (dt == VALLE_BF16) && B <= 32 && (d == 256 || d == 1024) && (f == 1024 || f == 4096) &&
+    const bool wavepath = (dt == VALLE_BF16) && B <= 32 && (d == 256 || d == 512 || d == 768 || d == 1024) && f == 4 * d &&
                           m->layers[0].pn_qkv && m->layers[0].p_o && m->layers[0].pn_gu && m->layers[0].p_down && m->head_pn[st->head];
     int rc;
     for (int step = 0; step < n_steps; ++step) {
