@@ -97,11 +97,13 @@ def get_ref_model(kind, dtype=torch.float32, **synth_kw):
     if key in _models:
         return _models[key]
     mcfg = {"full": vcfg.repo_default_model, "tiny": vcfg.tiny_model, "tiny_len": vcfg.tiny_len_model,
-            "tiny_nc": vcfg.tiny_nc_model, "tiny_tone": vcfg.tiny_tone_model, "tiny_upi": vcfg.tiny_upi_model, "tiny_nobias": vcfg.tiny_nobias_model, "tiny_nc_upi": vcfg.tiny_nc_upi_model}[kind]()
+            "tiny_nc": vcfg.tiny_nc_model, "tiny_tone": vcfg.tiny_tone_model, "tiny_upi": vcfg.tiny_upi_model, "tiny_nobias": vcfg.tiny_nobias_model, "tiny_nc_upi": vcfg.tiny_nc_upi_model, "tiny_nosum": vcfg.tiny_nosum_model}[kind]()
     model = rh.build_reference_model(size=mcfg.size, capabilities=list(mcfg.capabilities),
                                      noncausal_masks=mcfg.experimental.noncausal_masks,
                                      unified_position_ids=mcfg.experimental.unified_position_ids,
-                                     classifiers_bias=mcfg.experimental.classifiers_bias)
+                                     classifiers_bias=mcfg.experimental.classifiers_bias,
+                                     audio_embedding_sums=mcfg.experimental.audio_embedding_sums)
+    assert model.resps_emb.sums == mcfg.experimental.audio_embedding_sums
     assert model.noncausal_masks == mcfg.experimental.noncausal_masks
     assert model.unified_position_ids == mcfg.experimental.unified_position_ids
     synth_kw = dict(synth_kw)
@@ -694,6 +696,8 @@ def scen_tiny_unified_positions():
     narlen_scenario("tiny_nc_upi_narlen", "tiny_nc_upi", phns, proms, langs, lens=[15, 21], max_steps=5)
     # classifiers_bias=False: heads without a bias vector
     ar_nar_scenario("tiny_nobias_ar_nar", "tiny_nobias", mk, 191, steps=10)
+    # audio_embedding_sums=False: prompt and response frames embedded by their last known level alone
+    ar_nar_scenario("tiny_nosum_ar_nar", "tiny_nosum", mk, 211, steps=10)
 
 
 def scen_full_b1():

@@ -314,6 +314,8 @@ class Oracle:
         self.unified_pos = cfg.experimental.unified_position_ids
         self.emb_names, _, self.cls_names, self.cls_tokens = classifier_layout(cfg)
         self.eps = 1e-6
+        v = cfg.experimental.audio_embedding_sums                  # True / False / "prom" / "resp" (base.py:434, :438)
+        self.sums = {"proms_emb": v is True or v == "prom", "resps_emb": v is True or v == "resp"}
         self.theta = 10000.0
         self.inv_freq = 1.0 / (self.theta ** (torch.arange(0, self.Dh, 2, dtype=torch.int64).float() / self.Dh))
         if threads:
@@ -324,7 +326,7 @@ class Oracle:
 
     def _audio_sum(self, table_prefix, first, codes, n):
         acc = None
-        for l in range(n):
+        for l in (range(n) if self.sums[table_prefix] else (n - 1,)):                  # sums=False: the last level alone (base.py:169-173)
             e = self.w[f"{table_prefix}.embeddings.{first + l}.weight"][codes[:, l]]
             acc = e if acc is None else acc + e
         return acc

@@ -524,6 +524,11 @@ def test_tiny_classifiers_without_bias(gpu_device):
     assert all(f.shape == (9, 8) for f in full)
 
 
+def test_tiny_audio_embeddings_not_summed(gpu_device):
+    """audio_embedding_sums=False (the reference's dataclass default): one embedding row per frame in the gather plan."""
+    _ar_nar("tiny_nosum", "tiny_nosum_ar_nar")
+
+
 def test_edge_shapes_match_oracle(gpu_device):
     """Smallest and most ragged shapes: no prompt, one-phoneme text, one AR step, one-frame NAR, batch of one."""
     m, o = hip_model("tiny"), oracle("tiny")

@@ -364,6 +364,16 @@ def test_tiny_classifiers_without_bias():
     _ar_nar("tiny_nobias", "tiny_nobias_ar_nar")
 
 
+def test_tiny_audio_embeddings_not_summed():
+    """audio_embedding_sums=False (the reference's dataclass default): AR and the seven NAR levels."""
+    _ar_nar("tiny_nosum", "tiny_nosum_ar_nar")
+    z = load_golden("tiny_nosum_ar_nar")                       # the switch matters: the summed model decodes other codes
+    phns, proms, langs = golden_inputs(z)
+    codes = [torch.from_numpy(z[f"ar_codes_{b}"]) for b in range(len(phns))]
+    summed = make_oracle("tiny").nar(phns, proms, langs, codes, temperature=0.0)
+    assert any((summed[b].numpy() != z[f"nar_codes_{b}"]).any() for b in range(len(phns)))
+
+
 def test_full_b1_configs0():
     """BASELINE.json configs[0]: repo-default model, data/qnt.enc prompt, greedy AR + NAR."""
     _ar_nar("full", "full_b1")

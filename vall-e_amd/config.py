@@ -16,7 +16,7 @@ from pathlib import Path
 class ModelExperimentalSettings:
     # vall_e/config.py:271-298 (same names, same defaults)
     split_classifiers: bool = False
-    audio_embedding_sums: bool = False
+    audio_embedding_sums: bool | str = False      # True, False, "prom" or "resp" (base.py:434, :438)
     unified_position_ids: bool = True
     causal_size: int = 1
     masking_ratio: float | str = 0.8
@@ -162,6 +162,14 @@ def tiny_nobias_model(**kw) -> Model:
     """``tiny_model`` with ``classifiers_bias=False``: heads without a bias vector (base.py:179-199)."""
     m = tiny_model(**kw)
     m.experimental.classifiers_bias = False
+    return m
+
+
+def tiny_nosum_model(**kw) -> Model:
+    """``tiny_model`` with the reference's dataclass default ``audio_embedding_sums=False`` (config.py:291; data/config.yaml
+    switches it on): a code frame is embedded by its last known level alone (base.py:169-173)."""
+    m = tiny_model(**kw)
+    m.experimental.audio_embedding_sums = False
     return m
 
 

@@ -450,13 +450,18 @@ class AR_NAR(Base):
         cols = [known_d.view(total, level0)[:, l].contiguous() for l in range(level0)]         # int32 codes per level
         for n, q in enumerate(levels):
             plan, rows, dev = plans.pop(n)
-            dev[0][dev[3].long(), :q] = resp_idx[:, :q]                                        # patch: sum of levels < q
+            def patch(d):                                                                      # the codes decoded since planning
+                if self.sum_resp_levels:
+                    d[0][d[3].long(), :q] = resp_idx[:, :q]                                    # sum of levels < q
+                else:
+                    d[0][d[3].long(), 0] = resp_idx[:, q - 1]                                  # level q - 1 alone (base.py:169-173)
+            patch(dev)
             logits = self.forward_dense(plan, rows, dev=dev)
             prepare(n + 1)
             V = self.cls_tokens[plan.head]
             if cfg_strength > 0:
                 nplan, nrows, ndev = nplans.pop(n)
-                ndev[0][ndev[3].long(), :q] = resp_idx[:, :q]
+                patch(ndev)
                 null = self.forward_dense(nplan, nrows, dev=ndev)
                 self.cfg_combine(logits, null, V, off, cfg_strength, cfg_rescale)
             sp.offset = 1000 + n

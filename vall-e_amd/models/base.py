@@ -74,8 +74,8 @@ class Base:
         exp = config.experimental
         if config.arch_type != "llama":
             raise NotImplementedError(f"arch_type {config.arch_type!r}: only the llama stack is built")
-        if config.version != 5 or not exp.split_classifiers or exp.audio_embedding_sums is not True:
-            raise NotImplementedError("built for the repo-default model family: version 5, split classifiers, summed audio embeddings")
+        if config.version != 5 or not exp.split_classifiers:
+            raise NotImplementedError("built for the repo-default model family: version 5, split classifiers")
         if exp.causal_size != 1:
             raise NotImplementedError("causal_size != 1")
         if n_experts != 1:
@@ -95,6 +95,9 @@ class Base:
         self.version = config.version
         self.causal_size = exp.causal_size
         self.unified_position_ids = exp.unified_position_ids
+        # True / "prom" / "resp" (base.py:434, :438); without sums a frame is embedded by its last known level alone (:169-173)
+        self.sum_prom_levels = exp.audio_embedding_sums is True or exp.audio_embedding_sums == "prom"
+        self.sum_resp_levels = exp.audio_embedding_sums is True or exp.audio_embedding_sums == "resp"
         self.noncausal_masks = exp.noncausal_masks
         self.masking_ratio = exp.masking_ratio
         self.max_position_embeddings = exp.max_position_embeddings
@@ -364,8 +367,8 @@ class Base:
                     else:
                         n = 1 if q == 0 else q                                        # base.py:790-794
                         r = np.full((prom.shape[0], 8), -1, dtype=np.int32)
-                        for l in range(n):
-                            r[:, l] = off[f"prom{l}"] + prom[:, l]
+                        for j, l in enumerate(range(n) if self.sum_prom_levels else (n - 1,)):   # rows fill from column 0, -1 ends them
+                            r[:, j] = off[f"prom{l}"] + prom[:, l]
                         parts_p.append(r)
                 segs.append(("prom", np.concatenate(parts_p) if parts_p else np.zeros((0, 8), np.int32), n_tok))
             if "tone" in self.capabilities and tone_list is not None and tone_list[i] is not None:   # base.py:623-624, :672-673
@@ -385,8 +388,8 @@ class Base:
                     if resp.ndim == 1:
                         resp = resp[:, None]
                     r = np.full((resp.shape[0], 8), -1, dtype=np.int32)
-                    for l in range(q):
-                        r[:, l] = off[f"resp{l + 1}"] + resp[:, l]
+                    for j, l in enumerate(range(q) if self.sum_resp_levels else (q - 1,)):
+                        r[:, j] = off[f"resp{l + 1}"] + resp[:, l]
                     segs.append(("resp", r))
             parts, pos = [], []
             for j, seg in enumerate(segs):
