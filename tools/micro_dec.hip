@@ -50,7 +50,8 @@ int main(int argc, char** argv) {
     const int d = 1024, f = 4096, H = 16, L = 24;   // 24 layers of weights = 805 MB > 256 MiB MALL
     const int B = argc > 1 ? atoi(argv[1]) : 16;
     const int ctx = argc > 2 ? atoi(argv[2]) : 536;
-    const int CT = 768;
+    const int CT = (ctx + 1 <= 768 ? 768 : ((ctx + 1 + 63) / 64) * 64) + (getenv("MICRO_CT_PAD") ? atoi(getenv("MICRO_CT_PAD")) : 0);     // cache rows per (utterance, head): holds ctx + the new key
+    if (B < 1 || B > 32 || ctx < 1 || ctx > 8192) { printf("B in 1..32, ctx in 1..8192\n"); return 1; }
     (void)(argc > 3 ? atoi(argv[3]) : 0);                       // (argv[3] kept for old command lines)
     const bool force_eager = argc > 4 && atoi(argv[4]) != 0;   // counter runs: one dispatch record per kernel
     std::vector<bf16*> wqkv(L), wo(L), wgu(L), wdn(L), kc(L), vc(L);
@@ -122,7 +123,7 @@ int main(int argc, char** argv) {
     if (timeit("stream 6.3MB (192 blk x 32KB)", 6.29, true, [&](int l) { stream_kernel<32768><<<192, 256, 0, s>>>((const uint4*)wqkv[l], sink); return 0; })) return 1;
     if (timeit("stream 2MB (64 blk x 32KB)", 2.10, true, [&](int l) { stream_kernel<32768><<<64, 256, 0, s>>>((const uint4*)wo[l], sink); return 0; })) return 1;
     // KV-shaped streams over ONE layer's K cache (B*H regions of CT*128 B; the buffer holds exactly B*H*CT*128 B)
-    if (B == 16) {
+    if (B == 16 && CT == 768) {
         if (timeit("stream 25MB (256 blk x 96KB, 512thr)", 25.2, true, [&](int l) { stream2_kernel<98304, 512><<<256, 512, 0, s>>>((const uint4*)kc[l], sink, (size_t)98304 / 16); return 0; })) return 1;
         if (timeit("stream 25MB (256 blk x 96KB, 256thr)", 25.2, true, [&](int l) { stream2_kernel<98304, 256><<<256, 256, 0, s>>>((const uint4*)kc[l], sink, (size_t)98304 / 16); return 0; })) return 1;
         if (timeit("stream 25MB (512 blk x 48KB, 256thr)", 25.2, true, [&](int l) { stream2_kernel<49152, 256><<<512, 256, 0, s>>>((const uint4*)kc[l], sink, (size_t)49152 / 16); return 0; })) return 1;

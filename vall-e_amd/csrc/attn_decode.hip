@@ -2,7 +2,7 @@
 // (utterance, head) against ctx cached keys -- the KV-cache restatement of the reference's full
 // recompute (models/base.py:521 use_cache=False; SDPA call at models/arch/llama.py:448-456).
 //
-// HBM-bound: every cached K and V row is read exactly once.  One workgroup (8 or 16 waves) per
+// HBM-bound: every cached K and V row is read exactly once.  One workgroup (8 waves) per
 // (utterance, head); the keys of a pass are dealt to the waves in contiguous ranges and ALL of a
 // wave's K and V rows are requested up front (MAXC x 2 x 16 B per lane in flight), then consumed in
 // arrival order.  Lane mapping: 8 lanes share a key (16 B = 8 dims each), so one wave-instruction
@@ -150,9 +150,14 @@ int valle_attn_decode_bf16(const void* q, size_t q_row_stride, const void* kcach
     a.ctx_len = ctx_len; a.slot = cache_slot; a.out = (bf16*)out; a.H = H; a.cache_T = cache_T;
     a.ctx_extra = ctx_extra; a.out_frag = out_frag;
     dim3 grid(B, H);
-    // 16 waves x 6 chunks: 768 keys per pass (measured 2 % faster than 8 waves x 12); short caches in one pass
+    // Long caches: 8 waves x 6 chunks = 384 keys per pass.  At 94 VGPRs two such workgroups share a CU, so one's loads
+    // overlap the other's arithmetic; the 16-wave form (768 keys per pass, one workgroup per CU) measured 1-8 % slower
+    // from 330 to 2,000 cached positions (tools/run_attn_dec_variants.sh; VALLE_ATTN_DEC=0 brings it back, dev).
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("VALLE_ATTN_DEC"); variant = e ? atoi(e) : 1; }
     if (cache_T <= 8 * 8 * 8) attn_decode_bf16_kernel<8, 8><<<grid, 512, 0, s>>>(a);
-    else attn_decode_bf16_kernel<6, 16><<<grid, 1024, 0, s>>>(a);
+    else if (variant == 0) attn_decode_bf16_kernel<6, 16><<<grid, 1024, 0, s>>>(a);
+    else attn_decode_bf16_kernel<6, 8><<<grid, 512, 0, s>>>(a);
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
 }
