@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 export VALLE_ATTN_DEC=${V:-1}
-for cfg in "32 2000 0" "32 2000 8" "32 2000 24" "32 1000 0" "32 1000 8" "16 536 0" "16 536 8" "16 330 0"; do set -- $cfg
+for cfg in ${CFGS:-"32 2000 0" "32 1000 0" "16 536 0" "16 330 0"}; do set -- $cfg
   export MICRO_CT_PAD=$3
   rm -rf /tmp/adp
   timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/adp -- $R/tools/micro_dec $1 $2 0 1 > /tmp/adp.log 2>&1 || { tail -5 /tmp/adp.log; exit 1; }

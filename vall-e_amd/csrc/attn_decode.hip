@@ -152,7 +152,8 @@ int valle_attn_decode_bf16(const void* q, size_t q_row_stride, const void* kcach
     dim3 grid(B, H);
     // Long caches: 8 waves x 6 chunks = 384 keys per pass.  At 94 VGPRs two such workgroups share a CU, so one's loads
     // overlap the other's arithmetic; the 16-wave form (768 keys per pass, one workgroup per CU) measured 1-8 % slower
-    // from 330 to 2,000 cached positions (tools/run_attn_dec_variants.sh; VALLE_ATTN_DEC=0 brings it back, dev).
+    // from 330 to 2,000 cached positions (tools/run_attn_dec_variants.sh; VALLE_ATTN_DEC=0 brings it back, dev); 4 waves
+    // x 6 or x 12 chunks are no faster, and at 2,000 positions x 32 utterances every form takes 49.4 us = 5.3 TB/s.
     static int variant = -1;
     if (variant < 0) { const char* e = getenv("VALLE_ATTN_DEC"); variant = e ? atoi(e) : 1; }
     if (cache_T <= 8 * 8 * 8) attn_decode_bf16_kernel<8, 8><<<grid, 512, 0, s>>>(a);
