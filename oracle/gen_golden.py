@@ -613,6 +613,14 @@ def scen_tiny_task_prompt():
     d["ar_step_logits"] = torch.stack([torch.stack(c["logits"]) for c in rec.calls[:n_ar]])   # last row of every AR step
     d["pos_ids_0"] = pos0
     d["steps"], d["min_gap"] = np.int64(10), np.float64(gap)
+    # the same prompts under unified_position_ids=True: plain arange ids, nothing moves between steps
+    model, _ = get_ref_model("tiny_upi")
+    with Recorder(ref) as rec, torch.inference_mode():
+        upi = model(task_list=["tts"] * 2, phns_list=[p.clone() for p in phns], proms_list=mk(), lang_list=[l.clone() for l in langs],
+                    disable_tqdm=True, max_duration=10, temperature=0.0)
+    d.update(pack_list("upi_ar_codes", upi))
+    d["upi_ar_step_logits"] = torch.stack([torch.stack(c["logits"]) for c in rec.calls])
+    d["upi_min_gap"] = np.float64(min(top2_gap(r) for c in rec.calls for r in c["logits"]))
     save("tiny_task_prompt", **d)
 
 

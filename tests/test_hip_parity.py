@@ -443,6 +443,12 @@ def test_tiny_task_token_prompt(gpu_device):
     torch.testing.assert_close(torch.stack([l.cpu() for l in logits]), torch.from_numpy(z["ar_step_logits"]), rtol=2e-4, atol=2e-4)
     for b in range(B):
         np.testing.assert_array_equal(codes[b].cpu().numpy(), z[f"ar_codes_{b}"])
+    mu = hip_model("tiny_upi")                                  # unified ids: the KV-cache path, exact at every step
+    ucodes, ulogits = mu(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=int(z["steps"]),
+                         temperature=0.0, return_logits=True)
+    torch.testing.assert_close(torch.stack([l.cpu() for l in ulogits]), torch.from_numpy(z["upi_ar_step_logits"]), rtol=2e-4, atol=2e-4)
+    for b in range(B):
+        np.testing.assert_array_equal(ucodes[b].cpu().numpy(), z[f"upi_ar_codes_{b}"])
     guided = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=int(z["steps"]),
                temperature=0.0, cfg_strength=3.0)
     for b in range(B):

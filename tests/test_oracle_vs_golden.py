@@ -304,6 +304,11 @@ def test_tiny_task_token_prompt():
     guided, _ = o.ar(phns, proms, langs, max_duration=int(z["steps"]), temperature=0.0, cfg_strength=3.0, return_logits=True)
     for b in range(B):                                         # the null pass carries no prompt, hence no task token
         np.testing.assert_array_equal(guided[b].numpy(), z[f"ar_cfg_codes_{b}"])
+    ou = make_oracle("tiny_upi")                               # unified ids: arange, the same at every step
+    ucodes, ulogits = ou.ar(phns, proms, langs, max_duration=int(z["steps"]), temperature=0.0, return_logits=True)
+    assert_close(torch.stack(ulogits), z["upi_ar_step_logits"], 5e-4, 5e-4)
+    for b in range(B):
+        np.testing.assert_array_equal(ucodes[b].numpy(), z[f"upi_ar_codes_{b}"])
     # the newest token always sits at position id 1 and moves to its index + 1 one step later, so keys rotated once and
     # cached cannot reproduce the reference here: the oracle's cache mode is measurably off, recompute is not
     _, cached = o.ar(phns, proms, langs, max_duration=int(z["steps"]), temperature=0.0, return_logits=True, use_cache=True)
