@@ -530,6 +530,12 @@ def test_tiny_classifiers_without_bias(gpu_device):
     assert all(f.shape == (9, 8) for f in full)
 
 
+@pytest.mark.parametrize("kind", ["half2", "s075_2"])
+def test_other_width_presets_codes_identical(gpu_device, kind):
+    """Widths 512 and 768 against the reference's own goldens (fp32 codes and logits)."""
+    _ar_nar(kind, kind + "_ar_nar")
+
+
 def test_tiny_audio_embeddings_not_summed(gpu_device):
     """audio_embedding_sums=False (the reference's dataclass default): one embedding row per frame in the gather plan."""
     _ar_nar("tiny_nosum", "tiny_nosum_ar_nar")
@@ -616,8 +622,8 @@ def test_bf16_decode_batch_sizes_vs_oracle(gpu_device, B):
 def test_other_model_sizes_vs_oracle(gpu_device, kind, B):
     """The reference's other width presets (config.py:462-490: "half" = 512 / 8 heads, 0.75 = 768 / 12 heads; two layers
     here): fp32 dense logits against the oracle, then the fused bf16 decode kernels built for these widths, per-step
-    logits against the oracle's bf16 run, rel-L2 <= 4e-2 (the oracle is pinned by the reference at widths 256 and 1024;
-    nothing in it depends on the width)."""
+    logits against the oracle's bf16 run, rel-L2 <= 4e-2 (the oracle is pinned by the reference at these widths too:
+    goldens half2_ar_nar, s075_2_ar_nar)."""
     from vall_e_amd.synth import synth_batch
     import valle_oracle as vo
     phns, proms, langs = synth_batch(300 + B, B, n_phn=10, n_prom=12, ragged=True)

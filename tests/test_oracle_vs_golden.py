@@ -369,6 +369,12 @@ def test_tiny_classifiers_without_bias():
     _ar_nar("tiny_nobias", "tiny_nobias_ar_nar")
 
 
+@pytest.mark.parametrize("kind", ["half2", "s075_2"])
+def test_other_width_presets(kind):
+    """Widths 512 ("half") and 768 (0.75) of the reference's presets, two layers: AR + NAR against the reference."""
+    _ar_nar(kind, kind + "_ar_nar")
+
+
 def test_tiny_audio_embeddings_not_summed():
     """audio_embedding_sums=False (the reference's dataclass default): AR and the seven NAR levels."""
     _ar_nar("tiny_nosum", "tiny_nosum_ar_nar")
