@@ -290,3 +290,16 @@ def test_tts_text_front_end_ids(tmp_path):
     t = torch.tensor([1, 5, 2])
     assert tts.encode_text(t) is t
     assert tts.encode_lang("de").tolist() == [2] and tts.encode_lang("xx").tolist() == [0]
+
+
+def test_sequences_beyond_the_rope_table_are_refused():
+    """Positions index a RoPE table of max_position_embeddings rows: longer sequences raise instead of reading past it."""
+    import numpy as np
+    from vall_e_amd.models import get_model
+    from vall_e_amd import config as vcfg
+    cfg = vcfg.tiny_model()
+    cfg.experimental.max_position_embeddings = 64
+    m = get_model(cfg, training=False)
+    phn = torch.zeros(70, dtype=torch.uint8)
+    with pytest.raises(ValueError, match="max_position_embeddings"):
+        m.plan([phn], [torch.tensor([0], dtype=torch.uint8)], [None], [torch.zeros(0, dtype=torch.int64)], 0)

@@ -203,6 +203,9 @@ class AR_NAR(Base):
         for phns, proms in passes:
             plan = self.plan(phns, lang_list, proms, [torch.from_numpy(p) for p in prefix], 0)
             cache_T = _round_up(plan.max_T + n_steps + 1, 8)
+            if plan.max_T + n_steps + 1 > self.max_position_embeddings:       # the RoPE table has that many rows
+                raise ValueError(f"sequence of {plan.max_T} + {n_steps} steps exceeds max_position_embeddings "
+                                 f"({self.max_position_embeddings})")
             stride = B * H * cache_T * Dh
             kc = torch.empty((Lyr, B, H, cache_T, Dh), dtype=self.dtype, device=dev)
             vc = torch.empty_like(kc)

@@ -405,6 +405,8 @@ class Base:
                 pos = np.concatenate([pos, np.ones(idx.shape[0] - pos.shape[0], np.int32)])
             if self.unified_position_ids:
                 pos = np.arange(idx.shape[0], dtype=np.int32)
+            if idx.shape[0] > self.max_position_embeddings:                           # the RoPE table has that many rows
+                raise ValueError(f"sequence of {idx.shape[0]} rows exceeds max_position_embeddings ({self.max_position_embeddings})")
             idx_all.append(idx), pos_all.append(pos), lens.append(idx.shape[0])
             out_len.append(segs[-1][1].shape[0] if segs[-1][0] == out_kind else 0)
         head = "NAR:0:0" if timestep else ("AR:0:0" if q == 0 else f"NAR:{q-1}:{q}")
