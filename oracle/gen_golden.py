@@ -97,14 +97,15 @@ def get_ref_model(kind, dtype=torch.float32, **synth_kw):
     if key in _models:
         return _models[key]
     mcfg = {"full": vcfg.repo_default_model, "tiny": vcfg.tiny_model, "tiny_len": vcfg.tiny_len_model,
-            "tiny_nc": vcfg.tiny_nc_model, "tiny_tone": vcfg.tiny_tone_model, "tiny_upi": vcfg.tiny_upi_model, "tiny_nobias": vcfg.tiny_nobias_model, "tiny_nc_upi": vcfg.tiny_nc_upi_model, "tiny_nosum": vcfg.tiny_nosum_model,
+            "tiny_nc": vcfg.tiny_nc_model, "tiny_tone": vcfg.tiny_tone_model, "tiny_upi": vcfg.tiny_upi_model, "tiny_nobias": vcfg.tiny_nobias_model, "tiny_nc_upi": vcfg.tiny_nc_upi_model, "tiny_nosum": vcfg.tiny_nosum_model, "tiny_sumprom": vcfg.tiny_sumprom_model,
             "half2": lambda: vcfg.tiny_model(dim=512, heads=8), "s075_2": lambda: vcfg.tiny_model(dim=768, heads=12)}[kind]()
     model = rh.build_reference_model(size=mcfg.size, capabilities=list(mcfg.capabilities),
                                      noncausal_masks=mcfg.experimental.noncausal_masks,
                                      unified_position_ids=mcfg.experimental.unified_position_ids,
                                      classifiers_bias=mcfg.experimental.classifiers_bias,
                                      audio_embedding_sums=mcfg.experimental.audio_embedding_sums)
-    assert model.resps_emb.sums == mcfg.experimental.audio_embedding_sums
+    assert model.resps_emb.sums == (mcfg.experimental.audio_embedding_sums in (True, "resp"))
+    assert model.proms_emb.sums == (mcfg.experimental.audio_embedding_sums in (True, "prom"))
     assert model.noncausal_masks == mcfg.experimental.noncausal_masks
     assert model.unified_position_ids == mcfg.experimental.unified_position_ids
     synth_kw = dict(synth_kw)
@@ -707,6 +708,7 @@ def scen_tiny_unified_positions():
     ar_nar_scenario("tiny_nobias_ar_nar", "tiny_nobias", mk, 191, steps=10)
     # audio_embedding_sums=False: prompt and response frames embedded by their last known level alone
     ar_nar_scenario("tiny_nosum_ar_nar", "tiny_nosum", mk, 211, steps=10)
+    ar_nar_scenario("tiny_sumprom_ar_nar", "tiny_sumprom", mk, 241, steps=9)     # "prom": only the prompt side is summed
     # the other width presets (config.py:462-490), two layers: "half" = 512 / 8 heads, 0.75 = 768 / 12 heads
     ar_nar_scenario("half2_ar_nar", "half2", mk, 221, steps=9)
     ar_nar_scenario("s075_2_ar_nar", "s075_2", mk, 231, steps=9)

@@ -539,6 +539,7 @@ def test_other_width_presets_codes_identical(gpu_device, kind):
 def test_tiny_audio_embeddings_not_summed(gpu_device):
     """audio_embedding_sums=False (the reference's dataclass default): one embedding row per frame in the gather plan."""
     _ar_nar("tiny_nosum", "tiny_nosum_ar_nar")
+    _ar_nar("tiny_sumprom", "tiny_sumprom_ar_nar")
 
 
 def test_edge_shapes_match_oracle(gpu_device):

@@ -378,6 +378,7 @@ def test_other_width_presets(kind):
 def test_tiny_audio_embeddings_not_summed():
     """audio_embedding_sums=False (the reference's dataclass default): AR and the seven NAR levels."""
     _ar_nar("tiny_nosum", "tiny_nosum_ar_nar")
+    _ar_nar("tiny_sumprom", "tiny_sumprom_ar_nar")            # "prom": the prompt side summed, the response side not
     z = load_golden("tiny_nosum_ar_nar")                       # the switch matters: the summed model decodes other codes
     phns, proms, langs = golden_inputs(z)
     codes = [torch.from_numpy(z[f"ar_codes_{b}"]) for b in range(len(phns))]

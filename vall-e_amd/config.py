@@ -173,6 +173,13 @@ def tiny_nosum_model(**kw) -> Model:
     return m
 
 
+def tiny_sumprom_model(**kw) -> Model:
+    """``audio_embedding_sums="prom"``: prompt frames summed over their levels, response frames not (base.py:434, :438)."""
+    m = tiny_model(**kw)
+    m.experimental.audio_embedding_sums = "prom"
+    return m
+
+
 def tiny_nc_model(**kw) -> Model:
     """Tiny sibling of the published ``ar+nar-len-llama-8`` switches: ``len`` head and ``noncausal_masks``
     (NAR levels attend in both directions, base.py:1230-1233)."""
