@@ -5,6 +5,7 @@
 //   rocprofv3 --kernel-trace --stats -- ./tools/micro_dec
 #include "../vall-e_amd/csrc/common.h"
 #include <vector>
+#include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -77,14 +78,17 @@ int main(int argc, char** argv) {
     const int reps = force_eager ? 2 : 20;
 
     auto mkw = [&](const bf16* xx, int norm, const bf16* W, const bf16* resid, void* out, int ldo, int N, int K) {
-        DecWArgs a{}; a.x = xx; a.norm = norm; a.eps = 1e-6f; a.W = W; a.resid = resid; a.out = out; a.ldo = ldo; a.B = B; a.N = N; a.K = K; a.ssq_in = ssq; a.ssq_out = resid ? ssq : nullptr; return a; };
+        DecWArgs a{}; a.x = xx; a.norm = norm; a.eps = 1e-6f; a.W = W; a.resid = resid; a.out = out; a.ldo = ldo; a.B = B; a.N = N; a.K = K; return a; };
     auto w_qkv = [&](int l) { DecWArgs a = mkw(x, 1, wqkv[l], nullptr, qkv, 3 * d, 3 * d, d);
         a.rope_m = rope; a.ctx_len = ctxl; a.slot = nullptr; a.kc = kc[l]; a.vc = vc[l]; a.cache_T = CT; a.H = H; a.d = d;
         return valle_dec_wave_linear(a, DEC_EPI_QKV, s); };
     auto w_o = [&](int l) { return valle_dec_wave_linear(mkw(att, 0, wo[l], x, x, d, d, d), VALLE_EPI_RESID, s); };
     auto w_gu = [&](int l) { return valle_dec_wave_linear(mkw(x, 1, wgu[l], nullptr, ff, f, 2 * f, d), VALLE_EPI_GEGLU, s); };
     auto w_dn = [&](int l) { return valle_dec_wave_linear(mkw(ff, 0, wdn[l], x, x, d, d, f), VALLE_EPI_RESID, s); };
-    auto w_attn = [&](int l) { return valle_attn_decode_bf16(qkv, 3 * d, kc[l], vc[l], ctxl, nullptr, att, B, H, CT, 1, 1, s); };
+    auto w_attn = [&](int l) { return valle_attn_decode_bf16(qkv, 3 * d, kc[l], vc[l], ctxl, nullptr, att, B, H, CT, 1, 1, getenv("MICRO_HINT") ? ctx + 1 : 0, s); };
+    // MICRO_ALIAS=n: every layer uses the buffers of layer (l % n) -- with n = 1 or 2 the whole working set stays in the
+    // Infinity Cache: the time a perfect prefetcher could buy
+    if (getenv("MICRO_ALIAS")) { const int n = atoi(getenv("MICRO_ALIAS")); for (int l = 0; l < L; ++l) { wqkv[l] = wqkv[l % n]; wo[l] = wo[l % n]; wgu[l] = wgu[l % n]; wdn[l] = wdn[l % n]; kc[l] = kc[l % n]; vc[l] = vc[l % n]; } }
     auto wlayer = [&](int l) { int rc = w_qkv(l); rc |= w_attn(l); rc |= w_o(l); rc |= w_gu(l); rc |= w_dn(l); return rc; };
 
     // times `fn(l)` for l in 0..L-1 as one dependent chain; graph = captured once, replayed
@@ -136,6 +140,43 @@ int main(int argc, char** argv) {
         if (timeit("wave gate/up GEGLU", mb_gu, true, w_gu)) return 1;
         if (timeit("wave down", mb_dn, true, w_dn)) return 1;
     }
+#ifdef VALLE_STAMPS
+    {   // in-kernel timeline of a few layers in the middle of a warm eager chain (100 MHz ticks -> us)
+        const int NL = 3, NK = 5 * NL;
+        unsigned long long* sb; CK(hipMalloc(&sb, (size_t)NK * 4096 * 8));
+        for (int r = 0; r < 3; ++r) for (int l = 0; l < L; ++l) RC(wlayer(l));
+        CK(hipStreamSynchronize(s));
+        CK(hipMemset(sb, 0, (size_t)NK * 4096 * 8));
+        for (int l = 0; l < 8; ++l) RC(wlayer(l));
+        valle_stamp_buf = sb; valle_stamp_launch = 0;
+        for (int l = 8; l < 8 + NL; ++l) RC(wlayer(l));
+        valle_stamp_buf = nullptr;
+        for (int l = 8 + NL; l < L; ++l) RC(wlayer(l));
+        CK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> hs((size_t)NK * 4096);
+        CK(hipMemcpy(hs.data(), sb, hs.size() * 8, hipMemcpyDeviceToHost));
+        const char* names[5] = {"qkv", "attn", "o", "gu", "down"};
+        unsigned long long origin = ~0ull; double prev_end = 0;
+        for (int i = 0; i < 1024; ++i) if (hs[i * 4]) origin = std::min(origin, hs[i * 4]);
+        printf("launch  nWG | first-start (gap after prev end) | start spread | med loads-landed | med compute | med store-ack | last end   [us, rel. first launch]\n");
+        for (int k = 0; k < NK; ++k) {
+            std::vector<double> st, ld, cp, sa; double first = 1e30, lasts = 0, last_end = 0;
+            for (int i = 0; i < 1024; ++i) {
+                const unsigned long long* q = &hs[((size_t)k * 1024 + i) * 4];
+                if (!q[0]) continue;
+                const double a0 = (q[0] - origin) * 0.01, a1 = (q[1] - origin) * 0.01, a2 = (q[2] - origin) * 0.01, a3 = (q[3] - origin) * 0.01;
+                first = std::min(first, a0); lasts = std::max(lasts, a0); last_end = std::max(last_end, a3);
+                st.push_back(a0); ld.push_back(a1 - a0); cp.push_back(a2 - a1); sa.push_back(a3 - a2);
+            }
+            auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+            auto mx = [](std::vector<double>& v) { return v.empty() ? 0.0 : *std::max_element(v.begin(), v.end()); };
+            printf("%-5s %5zu | %7.2f (%5.2f) | %5.2f | %5.2f (max %5.2f) | %5.2f (max %5.2f) | %5.2f (max %5.2f) | %7.2f  dur %5.2f\n", names[k % 5], st.size(), first,
+                   k ? first - prev_end : 0.0, lasts - first, med(ld), mx(ld), med(cp), mx(cp), med(sa), mx(sa), last_end, last_end - first);
+            prev_end = last_end;
+        }
+        return 0;
+    }
+#endif
     const double mb_layer = mb_qkv + mb_o + mb_gu + mb_dn + mb_att;
     if (timeit("WAVE LAYER (5 kernels)", mb_layer, false, wlayer)) return 1;
     if (timeit("WAVE LAYER (5 kernels)", mb_layer, true, wlayer)) return 1;

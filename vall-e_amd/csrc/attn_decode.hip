@@ -2,98 +2,166 @@
 // (utterance, head) against ctx cached keys -- the KV-cache restatement of the reference's full
 // recompute (models/base.py:521 use_cache=False; SDPA call at models/arch/llama.py:448-456).
 //
-// HBM-bound: every cached K and V row is read exactly once.  One workgroup (8 waves) per
-// (utterance, head); the keys of a pass are dealt to the waves in contiguous ranges and ALL of a
-// wave's K and V rows are requested up front (MAXC x 2 x 16 B per lane in flight), then consumed in
-// arrival order.  Lane mapping: 8 lanes share a key (16 B = 8 dims each), so one wave-instruction
-// reads 8 whole 128-B rows = 1 KiB contiguous of the [slot][H][cache_T][64] cache.
+// HBM-bound: every cached K and V row is read exactly once.  One workgroup (NW waves) per
+// (utterance, head).  Keys go to the waves in chunks of 8 (chunk j of a pass: wave j % NW); a pass is
+// MAXC chunks per wave and the NEXT pass's K and V rows are requested before the current pass is
+// consumed (two register buffers), so up to 2 x MAXC x 2 x 16 B per lane are in flight.  Lane mapping:
+// 8 lanes share a key (16 B = 8 dims each), so one wave-instruction reads 8 whole 128-B rows = 1 KiB
+// contiguous of the [slot][H][cache_T][64] cache.  Arithmetic on packed bf16 pairs (v_dot2_f32_bf16):
+// q.k over dim pairs, P.V over KEY pairs (two chunks' V dwords interleaved by v_perm, the two probabilities
+// rounded to bf16 as the reference's bf16 SDPA does before its P.V matmul).
+// With a host bound on the number of keys (ctx_hi) the loads do not wait for ctx_len[b].
 #include "common.h"
 
+#ifdef VALLE_NO_NT
+#define LOAD_KV(p) (*(p))
+#else
+#define LOAD_KV(p) __builtin_nontemporal_load(p)   // every cached row is read once per step
+#endif
 struct AttnDecArgs {
     const bf16* q; size_t q_row_stride;          // q of utterance b: q + b*q_row_stride + h*64
     const bf16* k; const bf16* v;                // caches [slot][H][cache_T][64]
     const int32_t* ctx_len; const int32_t* slot;
     bf16* out;                                   // [B][H*64] row-major, or fragment order (dec_linear.hip)
     int H, cache_T, ctx_extra, out_frag;
+    int ctx_hi;                                  // host upper bound on ctx_len[b] + ctx_extra over the batch (0: none)
+#ifdef VALLE_STAMPS
+    unsigned long long* stamps;
+#endif
 };
+#ifdef VALLE_STAMPS
+unsigned long long* valle_stamp_buf = nullptr;
+int valle_stamp_launch = 0;
+#endif
 
 __device__ __forceinline__ float dpp_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }
 __device__ __forceinline__ float dpp_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }
 __device__ __forceinline__ float dpp_half_mirror(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)); }
 __device__ __forceinline__ float dpp_ror8(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true)); }
 
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2bf(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+
+// K and V rows of one pass: chunk c of wave w covers keys p0 + (c*NW + w)*8 .. +8; rows past `bound` re-read row bound-1
 template <int MAXC, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnDecArgs a) {
+__device__ __forceinline__ void attn_dec_issue(const bf16* kb, const bf16* vb, int p0, int wave, int g, int bound,
+                                               u32x4 (&kk)[MAXC], u32x4 (&vv)[MAXC]) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        int key = p0 + (c * NW + wave) * 8 + g;
+        key = key < bound ? key : bound - 1;
+        kk[c] = LOAD_KV(reinterpret_cast<const u32x4*>(kb + (size_t)key * 64));
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        int key = p0 + (c * NW + wave) * 8 + g;
+        key = key < bound ? key : bound - 1;
+        vv[c] = LOAD_KV(reinterpret_cast<const u32x4*>(vb + (size_t)key * 64));
+    }
+}
+
+// online-softmax update with one pass (scores in log2 units)
+template <int MAXC, int NW>
+__device__ __forceinline__ void attn_dec_consume(int p0, int wave, int g, int n_keys, const u32x4& qb,
+                                                 u32x4 (&kk)[MAXC], u32x4 (&vv)[MAXC], float& m, float& l, float (&o)[8]) {
+    static_assert(MAXC % 2 == 0, "chunks are consumed in pairs");
+    float s[MAXC];
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int key = p0 + (c * NW + wave) * 8 + g;
+        float t = dot2bf(kk[c].x, qb.x, 0.f);
+        t = dot2bf(kk[c].y, qb.y, t);
+        t = dot2bf(kk[c].z, qb.z, t);
+        t = dot2bf(kk[c].w, qb.w, t);
+        t += dpp_xor1(t);
+        t += dpp_xor2(t);
+        t += dpp_half_mirror(t);
+        s[c] = key < n_keys ? t * 1.44269504088896341f : -INFINITY;
+        mloc = fmaxf(mloc, s[c]);
+        if (key >= n_keys) vv[c] = u32x4{0u, 0u, 0u, 0u};     // rows past the context may hold anything (0 x NaN)
+    }
+    mloc = fmaxf(mloc, dpp_ror8(mloc));                                     // over the 8 key groups of the wave
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mn = fmaxf(m, mloc);
+    if (mn != -INFINITY) {                                                  // wave-uniform
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);                 // m = -inf -> 0
+        l *= alpha;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] *= alpha;
+#pragma unroll
+        for (int c = 0; c < MAXC; c += 2) {
+            const float pa = __builtin_amdgcn_exp2f(s[c] - mn), pb = __builtin_amdgcn_exp2f(s[c + 1] - mn);   // masked keys: 0
+            l += pa + pb;
+            const bf16x2_t pp = {(bf16)pa, (bf16)pb};
+            const uint32_t ppu = __builtin_bit_cast(uint32_t, pp);
+            const uint32_t va[4] = {vv[c].x, vv[c].y, vv[c].z, vv[c].w};
+            const uint32_t vb2[4] = {vv[c + 1].x, vv[c + 1].y, vv[c + 1].z, vv[c + 1].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t lo = __builtin_amdgcn_perm(vb2[i], va[i], 0x05040100u);   // (v_c[2i],   v_c+1[2i])
+                const uint32_t hi = __builtin_amdgcn_perm(vb2[i], va[i], 0x07060302u);   // (v_c[2i+1], v_c+1[2i+1])
+                o[2 * i] = dot2bf(lo, ppu, o[2 * i]);
+                o[2 * i + 1] = dot2bf(hi, ppu, o[2 * i + 1]);
+            }
+        }
+        m = mn;
+    }
+}
+
+template <int MAXC, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(const bf16* __restrict__ pQ, const bf16* __restrict__ pK,
+                                                                   const bf16* __restrict__ pV, const int32_t* __restrict__ pCtx,
+                                                                   const int32_t* __restrict__ pSlot, bf16* __restrict__ pOut,
+                                                                   int H, int cache_T, AttnDecArgs a) {
+    // the first 14 argument dwords arrive in SGPRs (kernarg preload, see the Makefile)
+#ifdef VALLE_STAMPS
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t1 = 0, t2 = 0;
+#endif
+    constexpr int PK = NW * 8 * MAXC;                                       // keys per pass
     const int b = blockIdx.x, h = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 3, sub = lane & 7;
-    const int sl = a.slot ? a.slot[b] : b;
-    const int n_keys = a.ctx_len[b] + a.ctx_extra;
-    const size_t base = ((size_t)sl * a.H + h) * a.cache_T * 64 + sub * 8;
-    const bf16* kb = a.k + base;
-    const bf16* vb = a.v + base;
-    uint4 qbits = *reinterpret_cast<const uint4*>(a.q + (size_t)b * a.q_row_stride + h * 64 + sub * 8);
+    const int sl = pSlot ? pSlot[b] : b;
+    const int n_keys = pCtx[b] + a.ctx_extra;                               // with ctx_hi: needed by the first consume only
+    const int bound = a.ctx_hi > 0 ? min(a.ctx_hi, cache_T) : n_keys;
+    const size_t base = ((size_t)sl * H + h) * cache_T * 64 + sub * 8;
+    const bf16* kb = pK + base;
+    const bf16* vb = pV + base;
+    u32x4 kA[MAXC], vA[MAXC], kB[MAXC], vB[MAXC];
+    attn_dec_issue<MAXC, NW>(kb, vb, 0, wave, g, bound, kA, vA);
+    u32x4 qb = *reinterpret_cast<const u32x4*>(pQ + (size_t)b * a.q_row_stride + h * 64 + sub * 8);
+    {   // q * 1/sqrt(64): exact in bf16
+        bf16x8 qv = __builtin_bit_cast(bf16x8, qb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = (bf16)((float)qv[e] * 0.125f);
+        qb = __builtin_bit_cast(u32x4, qv);
+    }
     float m = -INFINITY, l = 0.f, o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
 
-    for (int p0 = 0; p0 < n_keys; p0 += NW * 8 * MAXC) {
-        const int nk = min(n_keys - p0, NW * 8 * MAXC);                    // keys of this pass
-        const int per = ((nk + NW * 8 - 1) / (NW * 8)) * 8;                // keys per wave (multiple of 8)
-        const int k_lo = p0 + wave * per;
-        const int k_hi = min(p0 + nk, k_lo + per);
-        const int kmax = k_hi > k_lo ? k_hi - 1 : n_keys - 1;             // a wave without keys re-reads the last row
-        bf16x8 kv[MAXC], vv[MAXC];
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            int key = k_lo + c * 8 + g;
-            key = key < k_hi ? key : kmax;                                  // clamped: the load stays unconditional
-            kv[c] = *reinterpret_cast<const bf16x8*>(kb + (size_t)key * 64);
-        }
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            int key = k_lo + c * 8 + g;
-            key = key < k_hi ? key : kmax;
-            vv[c] = *reinterpret_cast<const bf16x8*>(vb + (size_t)key * 64);
-        }
-        __builtin_amdgcn_sched_barrier(0);          // every K and V row of the pass is in flight before any use
-        asm volatile("" : "+v"(qbits.x), "+v"(qbits.y), "+v"(qbits.z), "+v"(qbits.w));   // keeps the wait for q behind the loads above
-        const bf16x8 qv = __builtin_bit_cast(bf16x8, qbits);
-        float q[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) q[e] = (float)qv[e] * 0.125f;          // 1/sqrt(64), exact
-        float s[MAXC];
-        float mloc = -INFINITY;
-#pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            float t = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) t = fmaf(q[e], (float)kv[c][e], t);
-            t += dpp_xor1(t);
-            t += dpp_xor2(t);
-            t += dpp_half_mirror(t);
-            s[c] = (k_lo + c * 8 + g < k_hi) ? t : -INFINITY;
-            mloc = fmaxf(mloc, s[c]);
-        }
-        mloc = fmaxf(mloc, dpp_ror8(mloc));                                 // over the 8 key groups of the wave
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float mn = fmaxf(m, mloc);
-        if (mn != -INFINITY) {                                              // wave-uniform
-            const float alpha = expf(m - mn);                               // m = -inf -> 0
-            l *= alpha;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] *= alpha;
-#pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
-                const float p = expf(s[c] - mn);                            // masked keys: exp(-inf) = 0
-                l += p;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = fmaf(p, (float)vv[c][e], o[e]);
-            }
-            m = mn;
+    for (int p0 = 0; p0 < bound; p0 += 2 * PK) {
+        const bool more = p0 + PK < bound;                                  // wave-uniform
+        if (more) attn_dec_issue<MAXC, NW>(kb, vb, p0 + PK, wave, g, bound, kB, vB);
+#ifdef VALLE_STAMPS
+        if (p0 == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t1 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+        attn_dec_consume<MAXC, NW>(p0, wave, g, n_keys, qb, kA, vA, m, l, o);
+        if (more) {
+            if (p0 + 2 * PK < bound) attn_dec_issue<MAXC, NW>(kb, vb, p0 + 2 * PK, wave, g, bound, kA, vA);
+            attn_dec_consume<MAXC, NW>(p0 + PK, wave, g, n_keys, qb, kB, vB, m, l, o);
         }
     }
+#ifdef VALLE_STAMPS
+    t2 = __builtin_amdgcn_s_memrealtime();
+#endif
     // m is wave-uniform: the 8 key groups simply add up
     l += dpp_ror8(l);
     l += __shfl_xor(l, 16, 64);
@@ -125,7 +193,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnDecArgs a
 #pragma unroll
         for (int o = NW >> 1; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));   // lanes >= NW mirror lane NW-1: harmless
         mm = __shfl(mm, 0, 64);
-        const float scl = (mw == -INFINITY) ? 0.f : expf(mw - mm);
+        const float scl = (mw == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw - mm);
         float num = 0.f, den = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
@@ -134,31 +202,38 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(AttnDecArgs a
             den += __shfl(lw_l, w, 64) * sc;
         }
         const int col = h * 64 + threadIdx.x;
-        const size_t off = a.out_frag ? (size_t)(b >> 4) * 16 * a.H * 64 + (size_t)(((((col >> 5) << 6) + (((col >> 3) & 3) << 4) + (b & 15)) << 3) + (col & 7))
-                                      : (size_t)b * a.H * 64 + col;
-        a.out[off] = (bf16)(num / den);
+        const size_t off = a.out_frag ? (size_t)(b >> 4) * 16 * H * 64 + dec_frag_off<DEC_S_O>(b & 15, col, H * 64)
+                                      : (size_t)b * H * 64 + col;
+        pOut[off] = (bf16)(num / den);
+#ifdef VALLE_STAMPS
+        if (a.stamps) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+            if (threadIdx.x == 0) { unsigned long long* q = a.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4; q[0] = t0; q[1] = t1; q[2] = t2; q[3] = t3; }
+        }
+#endif
     }
 }
 
+#ifndef ATTN_DEC_MAXC      // dev overrides (tools/micro_dec builds)
+#define ATTN_DEC_MAXC 12
+#define ATTN_DEC_NW 8
+#endif
 int valle_attn_decode_bf16(const void* q, size_t q_row_stride, const void* kcache, const void* vcache,
                            const int32_t* ctx_len, const int32_t* cache_slot, void* out, int B, int H, int cache_T,
-                           int ctx_extra, int out_frag, hipStream_t s) {
+                           int ctx_extra, int out_frag, int ctx_hi, hipStream_t s) {
     VALLE_REQUIRE(q && kcache && vcache && ctx_len && out, VALLE_E_ARG, "valle_attn_decode: null pointer");
     if (B == 0) return VALLE_OK;
     AttnDecArgs a{};
     a.q = (const bf16*)q; a.q_row_stride = q_row_stride; a.k = (const bf16*)kcache; a.v = (const bf16*)vcache;
     a.ctx_len = ctx_len; a.slot = cache_slot; a.out = (bf16*)out; a.H = H; a.cache_T = cache_T;
     a.ctx_extra = ctx_extra; a.out_frag = out_frag;
+#ifdef VALLE_STAMPS
+    a.stamps = valle_stamp_next();
+#endif
+    a.ctx_hi = ctx_hi;
     dim3 grid(B, H);
-    // Long caches: 8 waves x 6 chunks = 384 keys per pass.  At 94 VGPRs two such workgroups share a CU, so one's loads
-    // overlap the other's arithmetic; the 16-wave form (768 keys per pass, one workgroup per CU) measured 1-8 % slower
-    // from 330 to 2,000 cached positions (tools/run_attn_dec_variants.sh; VALLE_ATTN_DEC=0 brings it back, dev); 4 waves
-    // x 6 or x 12 chunks are no faster, and at 2,000 positions x 32 utterances every form takes 49.4 us = 5.3 TB/s.
-    static int variant = -1;
-    if (variant < 0) { const char* e = getenv("VALLE_ATTN_DEC"); variant = e ? atoi(e) : 1; }
-    if (cache_T <= 8 * 8 * 8) attn_decode_bf16_kernel<8, 8><<<grid, 512, 0, s>>>(a);
-    else if (variant == 0) attn_decode_bf16_kernel<6, 16><<<grid, 1024, 0, s>>>(a);
-    else attn_decode_bf16_kernel<6, 8><<<grid, 512, 0, s>>>(a);
+    attn_decode_bf16_kernel<ATTN_DEC_MAXC, ATTN_DEC_NW><<<grid, ATTN_DEC_NW * 64, 0, s>>>(a.q, a.k, a.v, a.ctx_len, a.slot, a.out, a.H, a.cache_T, a);
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
 }

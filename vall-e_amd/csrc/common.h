@@ -91,8 +91,8 @@ struct SampleArgs {
     int prev_is_seq;            // prev tokens of row i = seq[i*seq_cap .. + seq_len[i])
     uint64_t step;              // added to the Philox offset
     // optional fused prologue of the NEXT decode step (wave-streaming path): embed the sampled token into the
-    // fragment-order x, its per-tile sums of squares and its RoPE position
-    const bf16* nx_emb; int nx_row0; bf16* nx_x; float* nx_ssq; int32_t* nx_pos; const int32_t* nx_pos0; int nx_d;
+    // fragment-order x and its RoPE position
+    const bf16* nx_emb; int nx_row0; bf16* nx_x; int32_t* nx_pos; const int32_t* nx_pos0; int nx_d;
     const float* nx_rope_tab; float* nx_rope;   // RoPE table [P][64] -> the new position's row, [32][64]
 };
 int valle_sample_launch(const SampleArgs& a, int rows, hipStream_t s);
@@ -102,23 +102,42 @@ int valle_sample_launch(const SampleArgs& a, int rows, hipStream_t s);
 #define GEMM_EPI_ROPE 5
 
 #define DEC_EPI_QKV 10
-// wave-streaming decode linears (dec_linear.hip): activations in fragment order, norm weight folded into W
+// wave-streaming decode linears (dec_linear.hip): activations in fragment order, norm weight folded into W.
+// Fragment order of a [16 utterances][K] activation matrix read by a linear with tile split S (dec_linear.hip):
+// K is cut into S parts of K' = K/S; a 1-KiB block = (32-wide k block b of K', utterance group g of C = 16/S) holds, for
+// MFMA lane (kq, j = part*C + m'), the 8 values x[g*C + m'][part*K' + b*32 + kq*8 ..].  S = 1 is the plain
+// [(k/32)][(k/8)%4][m][k%8] order.
+#define DEC_S_O 4       // o_proj reads the attention output in this order
+#define DEC_S_DOWN 4    // down_proj reads the GEGLU output in this order
+template <int S>
+__host__ __device__ __forceinline__ int dec_frag_off(int m, int k, int K) {
+    constexpr int C = 16 / S;
+    const int Kp = K / S, part = k / Kp, kk = k - part * Kp;
+    return (((((kk >> 5) * S + m / C) << 6) + (((kk >> 3) & 3) << 4) + part * C + (m % C)) << 3) + (k & 7);
+}
 struct DecWArgs {
     const bf16* x; const bf16* W; const float* bias; const bf16* resid;
     void* out; int ldo;
     int B, N, K;
     float eps; int norm;
-    const float* ssq_in;        // norm: [16][K/16] per-tile sums of squares of x's rows
-    float* ssq_out;             // RESID: [16][N/16] the same for the rows this kernel writes (may be NULL)
     const float* rope_m;        // QKV: [32][64] (cos, sin) row of every utterance's position
     const int32_t* ctx_len; const int32_t* slot;
     bf16* kc; bf16* vc; int cache_T; int H; int d;
+#ifdef VALLE_STAMPS
+    unsigned long long* stamps;
+#endif
 };
+#ifdef VALLE_STAMPS
+// dev-only in-kernel timestamps (tools/micro_dec_stamps): [launch][1024 workgroups][4] s_memrealtime ticks (100 MHz)
+extern unsigned long long* valle_stamp_buf;
+extern int valle_stamp_launch;
+static inline unsigned long long* valle_stamp_next() { return valle_stamp_buf ? valle_stamp_buf + (size_t)(valle_stamp_launch++) * 4096 : nullptr; }
+#endif
 int valle_dec_wave_linear(const DecWArgs& a, int epilogue, hipStream_t s);
 
 int valle_attn_decode_bf16(const void* q, size_t q_row_stride, const void* kcache, const void* vcache,
                            const int32_t* ctx_len, const int32_t* cache_slot, void* out, int B, int H, int cache_T,
-                           int ctx_extra, int out_frag, hipStream_t s);
+                           int ctx_extra, int out_frag, int ctx_hi, hipStream_t s);
 
 // attention launchers (ops_basic.hip)
 extern "C" int valle_attn_prefill_rowwise(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int M,

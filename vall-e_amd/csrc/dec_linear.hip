@@ -4,148 +4,204 @@
 // nn.Linear call sites replaced (one row per utterance, KV-cache step of models/ar_nar.py:748-848):
 // arch/llama.py:307-309 (q/k/v), :475 (o_proj), :492 (gate/up/down), models/base.py:217 (AR head).
 //
-// HBM-bound: the weights are read exactly once per step for the whole batch.  One WAVE owns a tile of
-// 16 weight rows x KW columns and streams it straight into registers (the pre-tiled streaming order of
-// valle_hip.h makes each wave-instruction a contiguous 1 KiB read whose bytes are already the MFMA A
-// fragment).  The <= 16 activation rows are kept in the same "fragment order" by every producer on the
-// decode path, so the B operand is 1 KiB-contiguous too and needs no LDS staging, no barrier:
-//     xfrag[(k/32)*64 + ((k/8)%4)*16 + m][k%8]  = x[m][k]     (one such [16][K] matrix per 16 utterances)
-// A tile's K range is split over the NWK waves of a workgroup (each streams its share into registers) and the
-// partial sums are reduced through LDS once: 2 waves at K = d_model, 8 at K = d_ff (shorter load queues and MFMA
-// chains per wave beat the single-wave form by ~6 % of the layer).
+// HBM-bound: the weights are read exactly once per step for the whole batch.  One WAVE owns a slice of a
+// tile's weight rows and streams it straight into registers (the pre-tiled streaming order of valle_hip.h
+// makes each wave-instruction a contiguous 1 KiB read whose bytes are already the MFMA A fragment).  The
+// <= 16 activation rows are kept in the matching "fragment order" by every producer on the decode path, so
+// the B operand is 1 KiB-contiguous too and needs no LDS staging (dec_frag_off in common.h).
 //
-// RMSNorm (arch/llama.py:64-77) is folded in: the norm weight is multiplied into W when the streaming
-// copy is built (valle_layer_weights.pn_*), and 1/rms(x[m]) scales the accumulator in the epilogue.
-// sum_k x[m][k]^2 arrives as per-tile partial sums written by whichever kernel produced x.
+// Tile shapes.  A launch streams fastest when every CU pulls an equal share of the weights, so a linear with
+// few output columns (o_proj, down_proj: N = d_model) uses NARROW tiles: with S = 4 a workgroup owns C = 16/S = 4
+// output columns and the 16 rows of its MFMA A operand are (K quarter ks, column c) pairs; the B operand's 16
+// columns are (K quarter ks', utterance m') pairs for one group of C utterances, and only the diagonal blocks
+// ks == ks' of the 16 x 16 product are kept (S MFMAs per k step, one per utterance group, all on the same A
+// registers).  N = 1,024 then gives 256 workgroups instead of 64.  S = 1 is the plain 16-column tile.
+// A tile's K' = K/S range is further split over the NWK waves of the workgroup; all partial sums (waves x
+// diagonal blocks) are reduced through LDS once.
+//
+// RMSNorm (arch/llama.py:64-77) is folded in: the norm weight is multiplied into W when the streaming copy
+// is built (valle_layer_weights.pn_*), and 1/rms(x[m]) -- computed from the activation registers the wave
+// holds anyway (v_dot2 on bf16 pairs), summed over the waves through LDS -- scales the accumulator.
 #include "common.h"
 
-__device__ __forceinline__ int frag_off(int m, int k) { return ((((k >> 5) << 6) + (((k >> 3) & 3) << 4) + m) << 3) + (k & 7); }
+// weights are read once per step by one CU: non-temporal loads keep them from displacing the activations in the
+// caches (measured on the layer chain, tools/micro_dec: 28.4 -> 28.1 us per layer)
+#ifdef VALLE_NO_NT_W
+#define LOAD_W(p) (*(p))
+#else
+#define LOAD_W(p) __builtin_nontemporal_load(p)
+#endif
 
-template <int EPI, int STEPS, int NWK, bool NORM, int MT>
-__global__ __launch_bounds__(64 * NWK) void dec_wave_kernel(DecWArgs a) {
+template <int EPI, int STEPS, int NWK, bool NORM, int MT, int S>
+__global__ __launch_bounds__(64 * NWK) void dec_wave_kernel(const bf16* __restrict__ pW, const bf16* __restrict__ pX,
+                                                            const bf16* pResid, void* pOut, int B, int N, float eps,
+                                                            DecWArgs a) {
+    // the first 11 argument dwords arrive in SGPRs (kernarg preload, see the Makefile): the weight and activation
+    // loads go out without waiting for a kernarg fetch; everything in `a` is needed behind the streams only
+#ifdef VALLE_STAMPS
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t1 = 0, t2 = 0;
+#endif
+    static_assert(!NORM || S == 1, "the norm prologue is built for plain tiles");
+    constexpr int C = 16 / S;                         // output columns per tile
+    constexpr int KS = STEPS * NWK;                   // 64-wide k steps per (virtual) weight row
+    constexpr int K = KS * 64 * S;                    // the linear's K
+    constexpr int P = NWK * S;                        // partial sums per output element
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int tile = blockIdx.x;
-    const int n = tile * 16 + fq * 4;                 // this lane's 4 consecutive output columns
-    constexpr int KS = STEPS * NWK;                   // 64-wide k steps per weight row
-    constexpr int K = KS * 64;
-    [[maybe_unused]] __shared__ float part[NWK > 1 ? NWK : 1][16][17];
+    const int n = tile * C + fq * 4;                  // this lane's 4 consecutive output columns (lanes with fq*4 < C)
+    const bool col_lane = fq * 4 < C;
+    [[maybe_unused]] __shared__ __attribute__((aligned(16))) float part[P > 1 ? P : 1][16][S == 1 ? C + 1 : C];
+    [[maybe_unused]] __shared__ float part_ss[NWK][16];
 
     f32x4 bs = {};
-    if constexpr (EPI == VALLE_EPI_F32OUT) {
-        if (a.bias) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bs[r] = (n + r < a.N) ? a.bias[n + r] : 0.f;
-        }
-    }
-    const bf16* wp = a.W + ((size_t)tile * KS + wave * STEPS) * 1024 + lane * 8;
+    const bf16* wp = pW + ((size_t)tile * KS + wave * STEPS) * 1024 + lane * 8;
     bf16x8 w0[STEPS], w1[STEPS];
     // utterances come in tiles of 16 (MT = 1 for up to 16, 2 for up to 32): the weight registers are loaded once
-    // and reused, every tile has its own fragment-order activation matrix (a.x + mt * 16 * K)
+    // and reused, every tile has its own fragment-order activation matrix (pX + mt * 16 * K)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m = mt * 16 + fr;                   // this lane's utterance
-        const int mc = m < a.B ? m : a.B - 1;         // clamped for side loads
-        // ---- 1. epilogue operands: issued first so they are back long before the weight stream ends
+        const int mc = m < B ? m : B - 1;             // clamped for side loads
+        // ---- 1. activations first (L2-resident, back quickly), then the weight stream
+        const bf16* xp = pX + (size_t)mt * 16 * K + ((size_t)wave * STEPS * 2 * S * 64 + lane) * 8;
+        bf16x8 xv[STEPS * 2][S];
+#pragma unroll
+        for (int s = 0; s < STEPS * 2; ++s)
+#pragma unroll
+            for (int g = 0; g < S; ++g) xv[s][g] = *reinterpret_cast<const bf16x8*>(xp + (s * S + g) * 512);
+        __builtin_amdgcn_sched_barrier(0);
+        if (mt == 0) {
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                w0[s] = LOAD_W(reinterpret_cast<const bf16x8*>(wp + s * 1024));
+                w1[s] = LOAD_W(reinterpret_cast<const bf16x8*>(wp + s * 1024 + 512));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- 2. epilogue operands: behind the streams (their pointers come from the kernarg segment), back long
+        // before the weights
         bf16x4 rs = {};
         f32x4 rp = {};
         int cpos = 0, csl = 0;
         if constexpr (EPI == VALLE_EPI_RESID) {
-            if (wave == 0) rs = *reinterpret_cast<const bf16x4*>(a.resid + (size_t)mt * 16 * a.N + frag_off(fr, n));
+            if (wave == 0 && col_lane) rs = *reinterpret_cast<const bf16x4*>(pResid + (size_t)mt * 16 * N + dec_frag_off<1>(fr, n, N));
+        } else if constexpr (EPI == VALLE_EPI_F32OUT) {
+            if (mt == 0 && a.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bs[r] = (n + r < N) ? a.bias[n + r] : 0.f;
+            }
         } else if constexpr (EPI == DEC_EPI_QKV) {
             cpos = a.ctx_len[mc];
             csl = a.slot ? a.slot[mc] : mc;
             rp = *reinterpret_cast<const f32x4*>(a.rope_m + (size_t)mc * 64 + (n & 63));   // (cos,sin) of pairs n/2, n/2+1
         }
-        // ---- 2. per-row sum of squares: partial sums per 16-column tile, left by the producer of x
-        // (ssq[m][K/16]); this lane adds tiles fq*STEPS .. +STEPS of its row
-        f32x4 sq[NORM ? KS / 4 : 1];
+        // ---- 3. sum of squares of this wave's K share of row m (the activations are back first)
+        [[maybe_unused]] float ss = 0.f;
         if constexpr (NORM) {
 #pragma unroll
-            for (int i = 0; i < KS / 4; ++i)
-                sq[i] = *reinterpret_cast<const f32x4*>(a.ssq_in + (size_t)m * (KS * 4) + fq * KS + i * 4);
-        }
-        // ---- 3. activations first (L2-resident, back quickly), then the weight stream: a wave can have 64
-        // vector-memory instructions outstanding, exactly the 32 + 32 of a K = 1024 tile
-        const bf16* xp = a.x + (size_t)mt * 16 * K + ((size_t)wave * STEPS * 128 + lane) * 8;
-        bf16x8 x0[STEPS], x1[STEPS];
+            for (int s = 0; s < STEPS * 2; ++s) {
+                const bf16x8 v = xv[s][0];
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            x0[s] = *reinterpret_cast<const bf16x8*>(xp + s * 1024);
-            x1[s] = *reinterpret_cast<const bf16x8*>(xp + s * 1024 + 512);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (mt == 0) {
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                w0[s] = *reinterpret_cast<const bf16x8*>(wp + s * 1024);
-                w1[s] = *reinterpret_cast<const bf16x8*>(wp + s * 1024 + 512);
+                for (int e = 0; e < 4; ++e) {
+                    const bf16x2 pr = {v[2 * e], v[2 * e + 1]};
+                    ss = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, ss, false);
+                }
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        float scale = 1.f;
-        if constexpr (NORM) {
-            float ss = 0.f;
-#pragma unroll
-            for (int i = 0; i < KS / 4; ++i) ss += (sq[i][0] + sq[i][1]) + (sq[i][2] + sq[i][3]);
             ss += __shfl_xor(ss, 16, 64);
             ss += __shfl_xor(ss, 32, 64);
-            scale = 1.0f / sqrtf(ss * (1.0f / (float)K) + a.eps);
-        }
-        // ---- 4. the product
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[s], x0[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[s], x1[s], acc, 0, 0, 0);
-        }
-        if constexpr (NWK > 1) {
-            if (mt > 0) __syncthreads();              // the previous tile's partial sums have been consumed
-#pragma unroll
-            for (int r = 0; r < 4; ++r) part[wave][fq * 4 + r][fr] = acc[r];
-            __syncthreads();
-            if (wave == 0) {
-#pragma unroll
-                for (int w = 1; w < NWK; ++w)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] += part[w][fq * 4 + r][fr];
+            if constexpr (NWK > 1) {
+                if (mt > 0) __syncthreads();
+                if (fq == 0) part_ss[wave][fr] = ss;
             }
         }
-        if (wave != 0 || m >= a.B) continue;          // (with NWK == 1 every wave is wave 0 of its own workgroup)
-        if constexpr (NORM) {
+#ifdef VALLE_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t1 = __builtin_amdgcn_s_memrealtime();
+#endif
+        // ---- 4. the product
+        f32x4 acc[S];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] *= scale;
+        for (int g = 0; g < S; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+#pragma unroll
+            for (int g = 0; g < S; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[s], xv[2 * s][g], acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < S; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[s], xv[2 * s + 1][g], acc[g], 0, 0, 0);
+        }
+        f32x4 sum = acc[0];
+        if constexpr (P > 1) {
+            // acc[g][r] is (row fq*4 + r, column fr) of the product for utterance group g: row = (K part, column c),
+            // column = (K part, utterance); the diagonal blocks go to LDS as part[wave*S + K part][utterance][c .. c+3]
+            if (mt > 0 && !(NORM && NWK > 1)) __syncthreads();   // the previous tile's partial sums have been consumed
+            const int ks_i = (fq * 4) / C, ks_j = fr / C;
+            if (ks_i == ks_j) {
+#pragma unroll
+                for (int g = 0; g < S; ++g) {
+                    float* q = &part[wave * S + ks_i][g * C + (fr % C)][(fq * 4) % C];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q[r] = acc[g][r];
+                }
+            }
+            __syncthreads();
+            if constexpr (S == 4) {
+                // 4 columns x P partial sums per utterance: the four lane groups share the partial sums, then fold
+                if (wave == 0) {
+                    sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int p = 0; p < P; p += 4) sum += *reinterpret_cast<const f32x4*>(&part[p + fq][fr][0]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sum[r] += __shfl_xor(sum[r], 16, 64);
+                        sum[r] += __shfl_xor(sum[r], 32, 64);
+                    }
+                }
+            } else if (wave == 0 && col_lane) {
+                sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sum[r] += part[p][fr][fq * 4 + r];
+            }
+        }
+#ifdef VALLE_STAMPS
+        t2 = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (wave != 0 || !col_lane || m >= B) continue;   // (with NWK == 1 every wave is wave 0 of its own workgroup)
+        if constexpr (NORM) {
+            if constexpr (NWK > 1) {
+                ss = 0.f;
+#pragma unroll
+                for (int w = 0; w < NWK; ++w) ss += part_ss[w][fr];
+            }
+            const float scale = 1.0f / sqrtf(ss * (1.0f / (float)K) + eps);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum[r] *= scale;
         }
         // ---- 5. epilogue: lane = utterance m, columns n .. n+3
         if constexpr (EPI == VALLE_EPI_RESID) {
             bf16x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16)((float)rs[r] + (float)(bf16)acc[r]);
-            *reinterpret_cast<bf16x4*>((bf16*)a.out + (size_t)mt * 16 * a.N + frag_off(fr, n)) = o;
-            if (a.ssq_out) {                          // this tile's share of sum_n x[m][n]^2 for the next RMSNorm
-                float q2 = 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) q2 = fmaf((float)o[r], (float)o[r], q2);
-                q2 += __shfl_xor(q2, 16, 64);
-                q2 += __shfl_xor(q2, 32, 64);
-                if (fq == 0) a.ssq_out[(size_t)m * (a.N >> 4) + tile] = q2;
-            }
+            for (int r = 0; r < 4; ++r) o[r] = (bf16)((float)rs[r] + (float)(bf16)sum[r]);
+            *reinterpret_cast<bf16x4*>((bf16*)pOut + (size_t)mt * 16 * N + dec_frag_off<1>(fr, n, N)) = o;
         } else if constexpr (EPI == VALLE_EPI_GEGLU) {
             bf16x2 o;
-            o[0] = (bf16)((float)(bf16)gelu_erf((float)(bf16)acc[0]) * (float)(bf16)acc[1]);
-            o[1] = (bf16)((float)(bf16)gelu_erf((float)(bf16)acc[2]) * (float)(bf16)acc[3]);
-            *reinterpret_cast<bf16x2*>((bf16*)a.out + (size_t)mt * 16 * (a.N >> 1) + frag_off(fr, n >> 1)) = o;
+            o[0] = (bf16)((float)(bf16)gelu_erf((float)(bf16)sum[0]) * (float)(bf16)sum[1]);
+            o[1] = (bf16)((float)(bf16)gelu_erf((float)(bf16)sum[2]) * (float)(bf16)sum[3]);
+            *reinterpret_cast<bf16x2*>((bf16*)pOut + (size_t)mt * 16 * (N >> 1) + dec_frag_off<DEC_S_DOWN>(fr, n >> 1, N >> 1)) = o;
         } else if constexpr (EPI == VALLE_EPI_F32OUT) {
-            float* o = (float*)a.out + (size_t)m * a.ldo + n;
+            float* o = (float*)pOut + (size_t)m * a.ldo + n;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (n + r < a.N) o[r] = acc[r] + bs[r];
+                if (n + r < N) o[r] = sum[r] + bs[r];
         } else if constexpr (EPI == DEC_EPI_QKV) {
             const int d = a.d;
             const int which = n / d, c = n - which * d, h = c >> 6, e = c & 63;
             bf16x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16)acc[r];
+            for (int r = 0; r < 4; ++r) o[r] = (bf16)sum[r];
             if (which < 2) {                          // RoPE on the two adjacent pairs (arch/llama.py:48-61)
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
@@ -156,69 +212,75 @@ __global__ __launch_bounds__(64 * NWK) void dec_wave_kernel(DecWArgs a) {
                 }
             }
             if (which == 0) {
-                *reinterpret_cast<bf16x4*>((bf16*)a.out + (size_t)m * a.ldo + n) = o;
+                *reinterpret_cast<bf16x4*>((bf16*)pOut + (size_t)m * a.ldo + n) = o;
             } else {
                 bf16* cp = (which == 1 ? a.kc : a.vc) + (((size_t)csl * a.H + h) * a.cache_T + cpos) * 64 + e;
                 *reinterpret_cast<bf16x4*>(cp) = o;
             }
         }
     }
+#ifdef VALLE_STAMPS
+    if (a.stamps && wave == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) { unsigned long long* q = a.stamps + (size_t)blockIdx.x * 4; q[0] = t0; q[1] = t1; q[2] = t2; q[3] = t3; }
+    }
+#endif
 }
 
-template <int EPI, int STEPS, int NWK, bool NORM>
-static int dec_wave_launch(const DecWArgs& a, hipStream_t s) {
-    if (a.B <= 16) dec_wave_kernel<EPI, STEPS, NWK, NORM, 1><<<ceil_div(a.N, 16), 64 * NWK, 0, s>>>(a);
-    else dec_wave_kernel<EPI, STEPS, NWK, NORM, 2><<<ceil_div(a.N, 16), 64 * NWK, 0, s>>>(a);
+template <int EPI, int STEPS, int NWK, bool NORM, int S>
+static int dec_wave_launch(const DecWArgs& a_in, hipStream_t s) {
+#ifdef VALLE_STAMPS
+    DecWArgs a = a_in; a.stamps = valle_stamp_next();
+#else
+    const DecWArgs& a = a_in;
+#endif
+    const int grid = ceil_div(a.N, 16 / S);
+    if (a.B <= 16) dec_wave_kernel<EPI, STEPS, NWK, NORM, 1, S><<<grid, 64 * NWK, 0, s>>>(a.W, a.x, a.resid, a.out, a.B, a.N, a.eps, a);
+    else dec_wave_kernel<EPI, STEPS, NWK, NORM, 2, S><<<grid, 64 * NWK, 0, s>>>(a.W, a.x, a.resid, a.out, a.B, a.N, a.eps, a);
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
 }
 
-// K-split of one 16-row tile over the waves of a workgroup.  Measured on the decode-layer chain (tools/micro_dec,
-// tools/run_dec_variants.sh, B = 16): 2 waves for K = 1024 and 8 waves for K = 4096 give 30.0 us per layer against
-// 31.8 us for (1, 4); more waves lose again to the LDS reduction; above 16 utterances K = 1024 stays on one wave
-// (B = 32: 40.1 vs 40.8 us per layer).  VALLE_DEC_NWK (1 | 2) / VALLE_DEC_NWK_DN (4 | 8) override (dev).
-static int dec_variant(int B) {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("VALLE_DEC_NWK"); v = e ? atoi(e) : 0; }
-    return v ? v : (B <= 16 ? 2 : 1);      // two 16-utterance tiles per wave (B > 16): one wave per tile is 40.1 vs 40.8 us
-}
-static int dec_variant_dn() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("VALLE_DEC_NWK_DN"); v = e ? atoi(e) : 8; }
-    return v;
-}
-#define DEC_K1024(EPI, NORM) \
-    switch (dec_variant(a.B)) { \
-        case 1: return dec_wave_launch<EPI, 16, 1, NORM>(a, s); \
-        default: return dec_wave_launch<EPI, 8, 2, NORM>(a, s); \
-    }
-
-// K = d_model in {256, 512, 768, 1024} (the reference's "quarter", "half", 0.75 and "full" sizes, config.py:462-469) for
-// the norm-prologue linears (QKV, gate/up, head) and o_proj; down_proj K = d_ff = 4 d_model.  Only the full size is tuned.
-#define DEC_KSMALL(EPI, NORM) \
-    if (K == 256) return dec_wave_launch<EPI, 4, 1, NORM>(a, s); \
-    if (K == 512) return dec_wave_launch<EPI, 8, 1, NORM>(a, s); \
-    if (K == 768) return dec_wave_launch<EPI, 12, 1, NORM>(a, s);
+// Shapes per linear (K' = K / S is split into NWK wave shares of STEPS 64-wide steps).  Measured on the decode-layer chain
+// (tools/micro_dec, B = 16, d_model 1,024; see profiles/README.md): only the full width is tuned, the other presets of the
+// reference (config.py:462-469: 256 "quarter", 512 "half", 768) take the same forms scaled down.
+#ifndef DEC_O_STEPS       // dev overrides (tools/micro_dec builds): -DDEC_O_STEPS=.. -DDEC_O_NWK=.. etc.
+#define DEC_O_STEPS 2
+#define DEC_O_NWK 2
+#endif
+#ifndef DEC_DN_STEPS
+#define DEC_DN_STEPS 2
+#define DEC_DN_NWK 8
+#endif
 int valle_dec_wave_linear(const DecWArgs& a, int epilogue, hipStream_t s) {
     VALLE_REQUIRE(a.B >= 1 && a.B <= 32, VALLE_E_UNSUPPORTED, "wave-streaming decode linears take 1..32 utterances, got %d", a.B);
     VALLE_REQUIRE(a.x && a.W && a.out, VALLE_E_ARG, "decode linear: null pointer");
     const int K = a.K;
+    const bool two = a.B <= 16;       // K = d_model on two waves up to 16 utterances, on one above (B = 32: 40.1 vs 40.8 us per layer)
     if (a.norm) {
+#define DEC_NORM_CASES(EPI) \
+        if (K == 256) return dec_wave_launch<EPI, 4, 1, true, 1>(a, s); \
+        if (K == 512) return dec_wave_launch<EPI, 8, 1, true, 1>(a, s); \
+        if (K == 768) return dec_wave_launch<EPI, 12, 1, true, 1>(a, s); \
+        if (K == 1024) return two ? dec_wave_launch<EPI, 8, 2, true, 1>(a, s) : dec_wave_launch<EPI, 16, 1, true, 1>(a, s);
         switch (epilogue) {
-            case VALLE_EPI_GEGLU: DEC_KSMALL(VALLE_EPI_GEGLU, true) if (K == 1024) DEC_K1024(VALLE_EPI_GEGLU, true) break;
-            case VALLE_EPI_F32OUT: DEC_KSMALL(VALLE_EPI_F32OUT, true) if (K == 1024) DEC_K1024(VALLE_EPI_F32OUT, true) break;
-            case DEC_EPI_QKV: DEC_KSMALL(DEC_EPI_QKV, true) if (K == 1024) DEC_K1024(DEC_EPI_QKV, true) break;
+            case VALLE_EPI_GEGLU: DEC_NORM_CASES(VALLE_EPI_GEGLU) break;
+            case VALLE_EPI_F32OUT: DEC_NORM_CASES(VALLE_EPI_F32OUT) break;
+            case DEC_EPI_QKV: DEC_NORM_CASES(DEC_EPI_QKV) break;
         }
     } else if (epilogue == VALLE_EPI_RESID) {
         VALLE_REQUIRE(a.resid != nullptr, VALLE_E_ARG, "decode linear: residual missing");
-        DEC_KSMALL(VALLE_EPI_RESID, false)
-        if (K == 1024) DEC_K1024(VALLE_EPI_RESID, false)
-        if (K == 2048) return dec_wave_launch<VALLE_EPI_RESID, 8, 4, false>(a, s);
-        if (K == 3072) return dec_wave_launch<VALLE_EPI_RESID, 12, 4, false>(a, s);
-        if (K == 4096) switch (dec_variant_dn()) {
-            case 4: return dec_wave_launch<VALLE_EPI_RESID, 16, 4, false>(a, s);
-            default: return dec_wave_launch<VALLE_EPI_RESID, 8, 8, false>(a, s);
-        }
+        VALLE_REQUIRE(a.N % 4 == 0, VALLE_E_ARG, "decode linear: N must be a multiple of 4");
+        constexpr int S = DEC_S_DOWN;   // == DEC_S_O: narrow tiles, K' = K / 4
+        static_assert(DEC_S_DOWN == 4 && DEC_S_O == 4, "the shape table below is written for S = 4");
+        if (K == 256) return dec_wave_launch<VALLE_EPI_RESID, 1, 1, false, S>(a, s);       // K' = 64
+        if (K == 512) return dec_wave_launch<VALLE_EPI_RESID, 1, 2, false, S>(a, s);       // 128
+        if (K == 768) return dec_wave_launch<VALLE_EPI_RESID, 1, 3, false, S>(a, s);       // 192
+        if (K == 1024) return dec_wave_launch<VALLE_EPI_RESID, DEC_O_STEPS, DEC_O_NWK, false, S>(a, s);   // 256
+        if (K == 2048) return dec_wave_launch<VALLE_EPI_RESID, 2, 4, false, S>(a, s);      // 512
+        if (K == 3072) return dec_wave_launch<VALLE_EPI_RESID, 2, 6, false, S>(a, s);      // 768
+        if (K == 4096) return dec_wave_launch<VALLE_EPI_RESID, DEC_DN_STEPS, DEC_DN_NWK, false, S>(a, s); // 1,024
     }
     valle_set_error("decode linear: combination not built (K=%d norm=%d epilogue=%d)", K, a.norm, epilogue);
     return VALLE_E_UNSUPPORTED;

@@ -77,13 +77,12 @@ __global__ __launch_bounds__(128) void dec_prepare_kernel(const T* __restrict__ 
         *reinterpret_cast<vec_t*>(x + (size_t)b * d + c) = *reinterpret_cast<const vec_t*>(src + c);
 }
 
-// wave-streaming decode path (dec_linear.hip): x in fragment order + per-tile sums of squares
+// wave-streaming decode path (dec_linear.hip): x in fragment order
 __global__ __launch_bounds__(128) void dec_prepare_frag_kernel(const bf16* __restrict__ emb, int emb_row0,
                                                                const int32_t* __restrict__ seq, int seq_cap,
                                                                const int32_t* __restrict__ seq_len,
                                                                const int32_t* __restrict__ resp_pos0,
-                                                               bf16* __restrict__ xf, float* __restrict__ ssq,
-                                                               int32_t* __restrict__ pos, int d,
+                                                               bf16* __restrict__ xf, int32_t* __restrict__ pos, int d,
                                                                const float* __restrict__ rope_tab, float* __restrict__ rope_m) {
     const int b = blockIdx.x;
     const int n = seq_len[b];
@@ -92,15 +91,8 @@ __global__ __launch_bounds__(128) void dec_prepare_frag_kernel(const bf16* __res
     if (threadIdx.x == 0) pos[b] = p;
     if (threadIdx.x < 64) rope_m[b * 64 + threadIdx.x] = rope_tab[(size_t)p * 64 + threadIdx.x];   // this position's (cos, sin) row
     const bf16* src = emb + (size_t)(emb_row0 + tok) * d;
-    for (int c = threadIdx.x * 8; c < d; c += 128 * 8) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c);
-        float q2 = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) q2 = fmaf((float)v[e], (float)v[e], q2);
-        q2 += __shfl_xor(q2, 1, 64);                                   // the two 8-column halves of a 16-column tile
-        *reinterpret_cast<bf16x8*>(xf + (size_t)(b >> 4) * 16 * d + ((((c >> 5) << 6) + (((c >> 3) & 3) << 4) + (b & 15)) << 3)) = v;
-        if ((threadIdx.x & 1) == 0) ssq[(size_t)b * (d >> 4) + (c >> 4)] = q2;
-    }
+    for (int c = threadIdx.x * 8; c < d; c += 128 * 8)
+        *reinterpret_cast<bf16x8*>(xf + (size_t)(b >> 4) * 16 * d + dec_frag_off<1>(b & 15, c, d)) = *reinterpret_cast<const bf16x8*>(src + c);
 }
 
 struct Carver {
@@ -189,7 +181,6 @@ extern "C" size_t valle_decode_workspace_bytes(const valle_model* m, int B) {
     t += align_up((size_t)B * f * es, 256);            // ff
     t += align_up((size_t)B * 2048 * sizeof(float), 256);  // logits
     t += align_up((size_t)(B + 1) * sizeof(int32_t), 256) * 2 + align_up((size_t)B * sizeof(int32_t), 256);
-    t += align_up((size_t)32 * (d / 16) * sizeof(float), 256);   // per-tile sums of squares (wave-streaming path)
     t += align_up((size_t)32 * d * es, 256) * 2 + align_up((size_t)32 * f * es, 256);  // its fragment-order x, att, ff (16-row tiles)
     t += align_up((size_t)32 * 64 * sizeof(float), 256);                // RoPE rows of the current positions
     return t;
@@ -217,7 +208,6 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
     float* lg_ws = (float*)ws.take((size_t)B * 2048 * sizeof(float));
     int32_t* pos = (int32_t*)ws.take((size_t)(B + 1) * sizeof(int32_t));
     int32_t* cu = (int32_t*)ws.take((size_t)(B + 1) * sizeof(int32_t));
-    float* ssq = (float*)ws.take((size_t)32 * (d / 16) * sizeof(float));
     // the wave-streaming path keeps its activations as 16-row fragment-order matrices (one or two of them)
     bf16* xf = (bf16*)ws.take((size_t)32 * d * es);
     bf16* attf = (bf16*)ws.take((size_t)32 * d * es);
@@ -235,7 +225,7 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
         if (wavepath && step > 0) {
             // the previous step's sampler already embedded its token (SampleArgs.nx_*)
         } else if (wavepath)
-            dec_prepare_frag_kernel<<<B, 128, 0, s>>>((const bf16*)m->emb, st->resp_emb_row0, st->seq, st->max_steps, st->seq_len, st->resp_pos0, xf, ssq, pos, d, m->rope, rope_m);
+            dec_prepare_frag_kernel<<<B, 128, 0, s>>>((const bf16*)m->emb, st->resp_emb_row0, st->seq, st->max_steps, st->seq_len, st->resp_pos0, xf, pos, d, m->rope, rope_m);
         else if (dt == VALLE_BF16)
             dec_prepare_kernel<bf16><<<B, 128, 0, s>>>((const bf16*)m->emb, st->resp_emb_row0, st->seq, st->max_steps, st->seq_len, st->resp_pos0, (bf16*)x, pos, cu, d, B);
         else
@@ -248,20 +238,20 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
             if (wavepath) {
                 DecWArgs a{};
                 a.x = xf; a.W = (const bf16*)w.pn_qkv; a.out = qkv; a.ldo = 3 * d; a.B = B; a.N = 3 * d; a.K = d;
-                a.eps = c.rms_eps; a.norm = 1; a.ssq_in = ssq;
+                a.eps = c.rms_eps; a.norm = 1;
                 a.rope_m = rope_m; a.ctx_len = st->ctx_len; a.slot = st->cache_slot;
                 a.kc = (bf16*)kc; a.vc = (bf16*)vc; a.cache_T = st->cache_T; a.H = H; a.d = d;
                 RUN(valle_dec_wave_linear(a, DEC_EPI_QKV, s));
-                RUN(valle_attn_decode_bf16(qkv, (size_t)3 * d, kc, vc, st->ctx_len, st->cache_slot, attf, B, H, st->cache_T, 1, 1, s));
+                RUN(valle_attn_decode_bf16(qkv, (size_t)3 * d, kc, vc, st->ctx_len, st->cache_slot, attf, B, H, st->cache_T, 1, 1, 0, s));
                 DecWArgs o{};
-                o.x = attf; o.W = (const bf16*)w.p_o; o.resid = xf; o.out = xf; o.B = B; o.N = d; o.K = d; o.ssq_out = ssq;
+                o.x = attf; o.W = (const bf16*)w.p_o; o.resid = xf; o.out = xf; o.B = B; o.N = d; o.K = d;
                 RUN(valle_dec_wave_linear(o, VALLE_EPI_RESID, s));
                 DecWArgs g{};
                 g.x = xf; g.W = (const bf16*)w.pn_gu; g.out = fff; g.B = B; g.N = 2 * f; g.K = d;
-                g.eps = c.rms_eps; g.norm = 1; g.ssq_in = ssq;
+                g.eps = c.rms_eps; g.norm = 1;
                 RUN(valle_dec_wave_linear(g, VALLE_EPI_GEGLU, s));
                 DecWArgs dn{};
-                dn.x = fff; dn.W = (const bf16*)w.p_down; dn.resid = xf; dn.out = xf; dn.B = B; dn.N = d; dn.K = f; dn.ssq_out = ssq;
+                dn.x = fff; dn.W = (const bf16*)w.p_down; dn.resid = xf; dn.out = xf; dn.B = B; dn.N = d; dn.K = f;
                 RUN(valle_dec_wave_linear(dn, VALLE_EPI_RESID, s));
             } else {
                 RUN(valle_rmsnorm(x, w.ln1, h, B, d, c.rms_eps, dt, s));
@@ -277,7 +267,7 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
         if (wavepath) {
             DecWArgs hd{};
             hd.x = xf; hd.W = (const bf16*)m->head_pn[st->head]; hd.bias = m->head_b[st->head]; hd.out = lg; hd.ldo = ldl;
-            hd.B = B; hd.N = st->vocab; hd.K = d; hd.eps = c.rms_eps; hd.norm = 1; hd.ssq_in = ssq;
+            hd.B = B; hd.N = st->vocab; hd.K = d; hd.eps = c.rms_eps; hd.norm = 1;
             RUN(valle_dec_wave_linear(hd, VALLE_EPI_F32OUT, s));
         } else {
             RUN(valle_rmsnorm(x, m->final_norm, h, B, d, c.rms_eps, dt, s));
@@ -288,7 +278,7 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
         sa.logits = lg; sa.ld = ldl; sa.vocab = st->vocab; sa.nar_mode = 0; sa.p = *sp;
         sa.ids = wavepath ? cu : pos;  // scratch: the token also lands in seq
         if (wavepath && step + 1 < n_steps) {
-            sa.nx_emb = (const bf16*)m->emb; sa.nx_row0 = st->resp_emb_row0; sa.nx_x = xf; sa.nx_ssq = ssq;
+            sa.nx_emb = (const bf16*)m->emb; sa.nx_row0 = st->resp_emb_row0; sa.nx_x = xf;
             sa.nx_pos = pos; sa.nx_pos0 = st->resp_pos0; sa.nx_d = d; sa.nx_rope_tab = m->rope; sa.nx_rope = rope_m;
         }
         sa.scores = st->scores;

@@ -377,12 +377,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
         const bf16* src = a.nx_emb + (size_t)(a.nx_row0 + tok) * a.nx_d;
         for (int c = tid * 8; c < a.nx_d; c += SAMP_THREADS * 8) {
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c);
-            float q2 = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) q2 = fmaf((float)v[e], (float)v[e], q2);
-            q2 += __shfl_xor(q2, 1, 64);
-            *reinterpret_cast<bf16x8*>(a.nx_x + (size_t)(item >> 4) * 16 * a.nx_d + ((((c >> 5) << 6) + (((c >> 3) & 3) << 4) + (item & 15)) << 3)) = v;
-            if ((tid & 1) == 0) a.nx_ssq[(size_t)item * (a.nx_d >> 4) + (c >> 4)] = q2;
+            *reinterpret_cast<bf16x8*>(a.nx_x + (size_t)(item >> 4) * 16 * a.nx_d + dec_frag_off<1>(item & 15, c, a.nx_d)) = v;
         }
         const int npos = (a.nx_pos0 ? a.nx_pos0[item] : 0) + n_prev;                  // position of token index n_prev
         if (tid == 0) a.nx_pos[item] = npos;
@@ -455,16 +450,11 @@ __global__ __launch_bounds__(64) void sample_greedy_wave_kernel(SampleArgs a) {
             if (tok == a.p.stop_token) a.stopped[item] = 1;
         }
     }
-    if (a.nx_x != nullptr) {                                    // next step's fragment-order x, ssq and position
+    if (a.nx_x != nullptr) {                                    // next step's fragment-order x and position
         const bf16* src = a.nx_emb + (size_t)(a.nx_row0 + tok) * a.nx_d;
         for (int c = lane * 8; c < a.nx_d; c += 64 * 8) {
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c);
-            float q2 = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) q2 = fmaf((float)v[e], (float)v[e], q2);
-            q2 += __shfl_xor(q2, 1, 64);
-            *reinterpret_cast<bf16x8*>(a.nx_x + (size_t)(item >> 4) * 16 * a.nx_d + ((((c >> 5) << 6) + (((c >> 3) & 3) << 4) + (item & 15)) << 3)) = v;
-            if ((lane & 1) == 0) a.nx_ssq[(size_t)item * (a.nx_d >> 4) + (c >> 4)] = q2;
+            *reinterpret_cast<bf16x8*>(a.nx_x + (size_t)(item >> 4) * 16 * a.nx_d + dec_frag_off<1>(item & 15, c, a.nx_d)) = v;
         }
         const int npos = (a.nx_pos0 ? a.nx_pos0[item] : 0) + n_prev;
         if (lane == 0) a.nx_pos[item] = npos;

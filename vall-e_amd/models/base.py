@@ -213,7 +213,7 @@ class Base:
             packed = [None] * 4
             if dt == torch.bfloat16 and d % 64 == 0:
                 for j, n in enumerate(("o", "down")):
-                    b[f"p_{n}{l}"] = pack_stream_order(b[f"{n}{l}"])
+                    b[f"p_{n}{l}"] = pack_stream_order(narrow_tile_rows(b[f"{n}{l}"], 4))
                     packed[j] = b[f"p_{n}{l}"].data_ptr()
                 # norm weight folded in (product in fp32 of the bf16-rounded factors, rounded to bf16 once)
                 for j, (n, ln) in enumerate((("qkv", "ln1_"), ("gu", "ln2_"))):
@@ -585,6 +585,15 @@ def pack_stream_order(w: torch.Tensor) -> torch.Tensor:
         w = torch.cat([w, w.new_zeros(Np - N, K)])
     t = w.reshape(Np // 16, 16, K // 64, 2, 4, 8)        # nt, fr, ks, half, fq, j
     return t.permute(0, 2, 3, 4, 1, 5).contiguous().reshape(-1)
+
+
+def narrow_tile_rows(w: torch.Tensor, S: int) -> torch.Tensor:
+    """[N][K] -> [N*S][K/S]: the rows of a 16-row tile are (K part, output column) pairs of 16/S output columns
+    (narrow tiles of o_proj / down_proj, csrc/dec_linear.hip; S == DEC_S_O == DEC_S_DOWN of csrc/common.h)."""
+    N, K = w.shape
+    C = 16 // S
+    assert N % C == 0 and K % (64 * S) == 0, (N, K, S)
+    return w.reshape(N // C, C, S, K // S).permute(0, 2, 1, 3).reshape(N * S, K // S).contiguous()
 
 
 def _np(t):
