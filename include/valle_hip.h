@@ -231,6 +231,9 @@ typedef struct {
     int32_t  resp_emb_row0;     /* row of resps_emb[0][0] in the concatenated table           */
     int      head;              /* classifier index (AR:0:0 = 0)                              */
     int      vocab;             /* columns of that head                                       */
+    int      max_ctx;           /* HOST-side upper bound on ctx_len[b] over the batch at the time of the call
+                                 * (required, > 0): valle_ar_decode refuses n_steps that would write past
+                                 * cache_T or read past the RoPE table -- the kernels do not check        */
 } valle_ar_state;
 
 size_t valle_decode_workspace_bytes(const valle_model* m, int B);

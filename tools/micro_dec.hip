@@ -85,10 +85,10 @@ int main(int argc, char** argv) {
     auto w_o = [&](int l) { return valle_dec_wave_linear(mkw(att, 0, wo[l], x, x, d, d, d), VALLE_EPI_RESID, s); };
     auto w_gu = [&](int l) { return valle_dec_wave_linear(mkw(x, 1, wgu[l], nullptr, ff, f, 2 * f, d), VALLE_EPI_GEGLU, s); };
     auto w_dn = [&](int l) { return valle_dec_wave_linear(mkw(ff, 0, wdn[l], x, x, d, d, f), VALLE_EPI_RESID, s); };
-    auto w_attn = [&](int l) { return valle_attn_decode_bf16(qkv, 3 * d, kc[l], vc[l], ctxl, nullptr, att, B, H, CT, 1, 1, getenv("MICRO_HINT") ? ctx + 1 : 0, s); };
+    auto w_attn = [&](int l) { return valle_attn_decode_bf16(qkv, 3 * d, kc[l], vc[l], ctxl, nullptr, att, B, H, CT, 1, 1, s); };
     // MICRO_ALIAS=n: every layer uses the buffers of layer (l % n) -- with n = 1 or 2 the whole working set stays in the
     // Infinity Cache: the time a perfect prefetcher could buy
-    if (getenv("MICRO_ALIAS")) { const int n = atoi(getenv("MICRO_ALIAS")); for (int l = 0; l < L; ++l) { wqkv[l] = wqkv[l % n]; wo[l] = wo[l % n]; wgu[l] = wgu[l % n]; wdn[l] = wdn[l % n]; kc[l] = kc[l % n]; vc[l] = vc[l % n]; } }
+    if (getenv("MICRO_ALIAS")) { const int n = atoi(getenv("MICRO_ALIAS")); for (int l = 0; l < L; ++l) { wqkv[l] = wqkv[l % n]; wo[l] = wo[l % n]; wgu[l] = wgu[l % n]; wdn[l] = wdn[l % n]; if (!getenv("MICRO_ALIAS_W")) { kc[l] = kc[l % n]; vc[l] = vc[l % n]; } } }   // MICRO_ALIAS_W: weights only
     auto wlayer = [&](int l) { int rc = w_qkv(l); rc |= w_attn(l); rc |= w_o(l); rc |= w_gu(l); rc |= w_dn(l); return rc; };
 
     // times `fn(l)` for l in 0..L-1 as one dependent chain; graph = captured once, replayed

@@ -10,7 +10,6 @@
 // contiguous of the [slot][H][cache_T][64] cache.  Arithmetic on packed bf16 pairs (v_dot2_f32_bf16):
 // q.k over dim pairs, P.V over KEY pairs (two chunks' V dwords interleaved by v_perm, the two probabilities
 // rounded to bf16 as the reference's bf16 SDPA does before its P.V matmul).
-// With a host bound on the number of keys (ctx_hi) the loads do not wait for ctx_len[b].
 #include "common.h"
 
 #ifdef VALLE_NO_NT
@@ -24,7 +23,6 @@ struct AttnDecArgs {
     const int32_t* ctx_len; const int32_t* slot;
     bf16* out;                                   // [B][H*64] row-major, or fragment order (dec_linear.hip)
     int H, cache_T, ctx_extra, out_frag;
-    int ctx_hi;                                  // host upper bound on ctx_len[b] + ctx_extra over the batch (0: none)
 #ifdef VALLE_STAMPS
     unsigned long long* stamps;
 #endif
@@ -129,8 +127,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(const bf16* _
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 3, sub = lane & 7;
     const int sl = pSlot ? pSlot[b] : b;
-    const int n_keys = pCtx[b] + a.ctx_extra;                               // with ctx_hi: needed by the first consume only
-    const int bound = a.ctx_hi > 0 ? min(a.ctx_hi, cache_T) : n_keys;
+    const int n_keys = pCtx[b] + a.ctx_extra;
+    const int bound = n_keys;   // (a host bound on the batch's longest context, so that the loads need not wait for ctx_len[b],
+                                // measured no faster: 8.74 vs 8.70 us)
     const size_t base = ((size_t)sl * H + h) * cache_T * 64 + sub * 8;
     const bf16* kb = pK + base;
     const bf16* vb = pV + base;
@@ -215,13 +214,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(const bf16* _
     }
 }
 
-#ifndef ATTN_DEC_MAXC      // dev overrides (tools/micro_dec builds)
-#define ATTN_DEC_MAXC 12
-#define ATTN_DEC_NW 8
-#endif
 int valle_attn_decode_bf16(const void* q, size_t q_row_stride, const void* kcache, const void* vcache,
                            const int32_t* ctx_len, const int32_t* cache_slot, void* out, int B, int H, int cache_T,
-                           int ctx_extra, int out_frag, int ctx_hi, hipStream_t s) {
+                           int ctx_extra, int out_frag, hipStream_t s) {
     VALLE_REQUIRE(q && kcache && vcache && ctx_len && out, VALLE_E_ARG, "valle_attn_decode: null pointer");
     if (B == 0) return VALLE_OK;
     AttnDecArgs a{};
@@ -231,9 +226,17 @@ int valle_attn_decode_bf16(const void* q, size_t q_row_stride, const void* kcach
 #ifdef VALLE_STAMPS
     a.stamps = valle_stamp_next();
 #endif
-    a.ctx_hi = ctx_hi;
     dim3 grid(B, H);
+    // Up to one workgroup per CU (B x H <= 256) a workgroup keeps 2 x 12 chunks per wave in flight; with more workgroups
+    // two of them share a CU (6-chunk passes, 138 VGPRs) and one's loads overlap the other's arithmetic.  Measured
+    // (tools/micro_dec, tools/time_configs.py): 16 utterances at 537 keys 8.70 vs 9.04 us per launch for 12 vs 6 chunks,
+    // 32 utterances at ~2,000 keys 808 vs 830 us per decode step for 6 vs 12; 16-wave workgroups lose in both (10.2-11.7 us).
+#ifdef ATTN_DEC_MAXC      // dev override (tools/micro_dec builds)
     attn_decode_bf16_kernel<ATTN_DEC_MAXC, ATTN_DEC_NW><<<grid, ATTN_DEC_NW * 64, 0, s>>>(a.q, a.k, a.v, a.ctx_len, a.slot, a.out, a.H, a.cache_T, a);
+#else
+    if (B * H <= 256) attn_decode_bf16_kernel<12, 8><<<grid, 512, 0, s>>>(a.q, a.k, a.v, a.ctx_len, a.slot, a.out, a.H, a.cache_T, a);
+    else attn_decode_bf16_kernel<6, 8><<<grid, 512, 0, s>>>(a.q, a.k, a.v, a.ctx_len, a.slot, a.out, a.H, a.cache_T, a);
+#endif
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
 }

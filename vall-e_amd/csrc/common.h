@@ -137,7 +137,7 @@ int valle_dec_wave_linear(const DecWArgs& a, int epilogue, hipStream_t s);
 
 int valle_attn_decode_bf16(const void* q, size_t q_row_stride, const void* kcache, const void* vcache,
                            const int32_t* ctx_len, const int32_t* cache_slot, void* out, int B, int H, int cache_T,
-                           int ctx_extra, int out_frag, int ctx_hi, hipStream_t s);
+                           int ctx_extra, int out_frag, hipStream_t s);
 
 // attention launchers (ops_basic.hip)
 extern "C" int valle_attn_prefill_rowwise(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int M,

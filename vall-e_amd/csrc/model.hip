@@ -9,6 +9,7 @@ extern "C" int valle_attn_prefill(const void* qkv, void* out, const int32_t* cu_
     return valle_attn_prefill_rowwise(qkv, out, cu_seqlens, B, M, H, Dh, causal, dtype, stream);
 }
 
+extern "C" void valle_model_destroy(valle_model* m);
 extern "C" int valle_model_create(const valle_config* cfg, const void* emb, const float* rope,
                                   const valle_layer_weights* layers_host, const void* final_norm,
                                   int n_cls, const void* const* head_w_host, const float* const* head_b_host,
@@ -18,16 +19,24 @@ extern "C" int valle_model_create(const valle_config* cfg, const void* emb, cons
                   VALLE_E_UNSUPPORTED, "valle_model_create: head_dim must be 64 (d_model %d, heads %d)", cfg->d_model, cfg->n_heads);
     VALLE_REQUIRE(cfg->d_model % 32 == 0 && cfg->d_ff % 32 == 0, VALLE_E_ARG, "valle_model_create: d_model/d_ff must be multiples of 32");
     VALLE_REQUIRE(cfg->dtype == VALLE_F32 || cfg->dtype == VALLE_BF16, VALLE_E_ARG, "valle_model_create: unknown dtype %d", cfg->dtype);
+    VALLE_REQUIRE(cfg->n_layers > 0 && n_cls >= 0 && cfg->max_pos > 0, VALLE_E_ARG,
+                  "valle_model_create: n_layers %d, n_cls %d, max_pos %d", cfg->n_layers, n_cls, cfg->max_pos);
+    VALLE_REQUIRE(n_cls == 0 || (head_w_host && head_n_host), VALLE_E_ARG, "valle_model_create: head tables missing");
     valle_model* m = (valle_model*)calloc(1, sizeof(valle_model));
     VALLE_REQUIRE(m, VALLE_E_ARG, "valle_model_create: out of host memory");
     m->cfg = *cfg;
     m->emb = emb; m->rope = rope; m->final_norm = final_norm; m->n_cls = n_cls;
     m->layers = (valle_layer_weights*)malloc(sizeof(valle_layer_weights) * cfg->n_layers);
-    memcpy(m->layers, layers_host, sizeof(valle_layer_weights) * cfg->n_layers);
     m->head_w = (const void**)malloc(sizeof(void*) * (n_cls > 0 ? n_cls : 1));
     m->head_b = (const float**)malloc(sizeof(float*) * (n_cls > 0 ? n_cls : 1));
     m->head_n = (int32_t*)malloc(sizeof(int32_t) * (n_cls > 0 ? n_cls : 1));
     m->head_pn = (const void**)malloc(sizeof(void*) * (n_cls > 0 ? n_cls : 1));
+    if (!m->layers || !m->head_w || !m->head_b || !m->head_n || !m->head_pn) {
+        valle_model_destroy(m);
+        valle_set_error("valle_model_create: out of host memory");
+        return VALLE_E_ARG;
+    }
+    memcpy(m->layers, layers_host, sizeof(valle_layer_weights) * cfg->n_layers);
     for (int k = 0; k < n_cls; ++k) {
         m->head_w[k] = head_w_host[k];
         m->head_b[k] = head_b_host ? head_b_host[k] : nullptr;
@@ -186,13 +195,21 @@ extern "C" size_t valle_decode_workspace_bytes(const valle_model* m, int B) {
     return t;
 }
 
-extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const valle_sample_params* sp,
-                               int n_steps, float* logits_out, int ld_logits,
-                               void* workspace, size_t workspace_bytes, void* stream) {
+static int ar_decode_impl(valle_model* m, const valle_ar_state* st, const valle_sample_params* sp,
+                          int n_steps, float* logits_out, int ld_logits,
+                          void* workspace, size_t workspace_bytes, void* stream) {
     VALLE_REQUIRE(m && st && workspace, VALLE_E_ARG, "valle_ar_decode: null pointer");
     VALLE_REQUIRE(sp != nullptr || n_steps == 1, VALLE_E_ARG, "valle_ar_decode: without sampler params only one step can run");
-    VALLE_REQUIRE(st->B > 0 && st->seq && st->seq_len && st->ctx_len && st->stopped && st->kcache && st->vcache,
+    VALLE_REQUIRE(n_steps >= 1, VALLE_E_ARG, "valle_ar_decode: n_steps %d", n_steps);
+    VALLE_REQUIRE(st->B > 0 && st->seq && st->seq_len && st->ctx_len && st->stopped && st->kcache && st->vcache && st->cache_slot,
                   VALLE_E_ARG, "valle_ar_decode: incomplete state");
+    // every step appends one key per utterance at ctx_len[b] and reads the RoPE row of its position (<= ctx_len[b]):
+    // the host's bound on the contexts keeps both inside the cache and the table
+    VALLE_REQUIRE(st->max_ctx > 0, VALLE_E_ARG, "valle_ar_decode: valle_ar_state.max_ctx (host bound on ctx_len) is required");
+    VALLE_REQUIRE((long)st->max_ctx + n_steps <= st->cache_T, VALLE_E_ARG,
+                  "valle_ar_decode: %d cached positions + %d steps exceed cache_T %d", st->max_ctx, n_steps, st->cache_T);
+    VALLE_REQUIRE((long)st->max_ctx + n_steps <= m->cfg.max_pos, VALLE_E_ARG,
+                  "valle_ar_decode: %d cached positions + %d steps exceed the RoPE table (%d rows)", st->max_ctx, n_steps, m->cfg.max_pos);
     VALLE_REQUIRE(st->head >= 0 && st->head < m->n_cls && st->vocab == m->head_n[st->head] && st->vocab <= 2048,
                   VALLE_E_ARG, "valle_ar_decode: bad head/vocab");
     VALLE_REQUIRE(logits_out == nullptr || ld_logits >= st->vocab, VALLE_E_ARG, "valle_ar_decode: ld_logits too small");
@@ -242,7 +259,7 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
                 a.rope_m = rope_m; a.ctx_len = st->ctx_len; a.slot = st->cache_slot;
                 a.kc = (bf16*)kc; a.vc = (bf16*)vc; a.cache_T = st->cache_T; a.H = H; a.d = d;
                 RUN(valle_dec_wave_linear(a, DEC_EPI_QKV, s));
-                RUN(valle_attn_decode_bf16(qkv, (size_t)3 * d, kc, vc, st->ctx_len, st->cache_slot, attf, B, H, st->cache_T, 1, 1, 0, s));
+                RUN(valle_attn_decode_bf16(qkv, (size_t)3 * d, kc, vc, st->ctx_len, st->cache_slot, attf, B, H, st->cache_T, 1, 1, s));
                 DecWArgs o{};
                 o.x = attf; o.W = (const bf16*)w.p_o; o.resid = xf; o.out = xf; o.B = B; o.N = d; o.K = d;
                 RUN(valle_dec_wave_linear(o, VALLE_EPI_RESID, s));
@@ -287,4 +304,10 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
         RUN(valle_sample_launch(sa, B, s));
     }
     return VALLE_OK;
+}
+
+extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const valle_sample_params* sp,
+                               int n_steps, float* logits_out, int ld_logits,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    return ar_decode_impl(m, st, sp, n_steps, logits_out, ld_logits, workspace, workspace_bytes, stream);
 }

@@ -367,7 +367,7 @@ int valle_attn_decode_launch(const void* qkv, const void* kcache, const void* vc
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(B, H);
     if (dtype == VALLE_BF16)      // the streaming bf16 kernel (attn_decode.hip), row-major output
-        return valle_attn_decode_bf16(qkv, (size_t)3 * d, kcache, vcache, ctx_len, cache_slot, out, B, H, cache_T, ctx_extra, 0, 0, s);
+        return valle_attn_decode_bf16(qkv, (size_t)3 * d, kcache, vcache, ctx_len, cache_slot, out, B, H, cache_T, ctx_extra, 0, s);
     if (dtype == VALLE_F32) attn_rowwise_kernel<float, true, 8, 4><<<grid, 512, 0, s>>>(a);
     else VALLE_REQUIRE(false, VALLE_E_ARG, "valle_attn_decode: unknown dtype %d", dtype);
     VALLE_LAUNCH_CHECK();

@@ -221,8 +221,8 @@ class AR_NAR(Base):
             resp_pos0 = self._i32([plan.lens[i] - len(prefix[i]) if self.unified_position_ids else 0 for i in range(B)])
             st = L.ARState(B, cap, seq.data_ptr(), seq_len.data_ptr(), ctx_len.data_ptr(), resp_pos0.data_ptr(),
                            slot.data_ptr(), stopped.data_ptr(), scores.data_ptr(), kc.data_ptr(), vc.data_ptr(),
-                           cache_T, stride, self._off["resp0"], 0, V)
-            states.append((st, (kc, vc, ctx_len, resp_pos0)))
+                           cache_T, stride, self._off["resp0"], 0, V, int(plan.max_T))
+            states.append((st, (kc, vc, ctx_len, resp_pos0), int(plan.max_T)))
             first_logits.append(lg)
         ws_bytes = lib.valle_decode_workspace_bytes(self._handle, B)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -242,6 +242,7 @@ class AR_NAR(Base):
                 n = min(step_chunk, n_steps - done)
                 lg_out = torch.empty((n, B, ld), dtype=torch.float32, device=dev) if return_logits else None
                 sp.offset = done
+                st.max_ctx = states[0][2] + done - 1          # every utterance has cached its prefill + (done - 1) tokens
                 if prof is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -270,6 +271,7 @@ class AR_NAR(Base):
                             hist[k][b, maxp - n_prefix[b]: maxp + 1] = first_logits[k][foff[b]:foff[b + 1]]
                     else:
                         lg = torch.empty((B, ld), dtype=torch.float32, device=dev)
+                        states[k][0].max_ctx = states[k][2] + step - 1
                         L.check(lib.valle_ar_decode(self._handle, C.byref(states[k][0]), None, 1, L.ptr(lg), ld,
                                                     L.ptr(ws), ws.numel(), stream))
                         hist[k][:, maxp + step] = lg
