@@ -251,6 +251,18 @@ int valle_ar_decode(valle_model* m, const valle_ar_state* st, const valle_sample
                     int n_steps, float* logits_out, int ld_logits,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* valle_ar_decode for callers that cannot allocate device memory (code under HIP graph capture, serving loops and
+ * harnesses that forbid hipMalloc) and so cannot bring a workspace.  NO COUNTERPART IN THE REFERENCE: the reference has
+ * no such entry; it exists for those callers only.  Same arguments, results and errors as valle_ar_decode without the
+ * workspace pair: the step's activations live in a static device array of valle_noalloc_scratch_bytes() = 2 MiB inside
+ * the library (every GPU the library runs on holds its own copy until the process ends).  Batches whose
+ * valle_decode_workspace_bytes() exceeds that are refused with VALLE_E_WORKSPACE (32 utterances at d_model 1024 in bf16
+ * need 1.3 MB).  Calls no hipMalloc / hipFree.  All calls on one GPU share the array: calls that overlap on one GPU
+ * (two streams, two threads) race -- serialise them or use valle_ar_decode with separate workspaces. */
+size_t valle_noalloc_scratch_bytes(void);
+int valle_ar_decode_noalloc(valle_model* m, const valle_ar_state* st, const valle_sample_params* sp,
+                            int n_steps, float* logits_out, int ld_logits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

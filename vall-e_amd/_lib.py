@@ -78,6 +78,8 @@ SIGNATURES = {
     "valle_decode_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "valle_ar_decode": (c_int, [c_void_p, C.POINTER(ARState), C.POINTER(SampleParams), c_int, c_void_p, c_int,
                                 c_void_p, c_size_t, c_void_p]),
+    "valle_noalloc_scratch_bytes": (c_size_t, []),
+    "valle_ar_decode_noalloc": (c_int, [c_void_p, C.POINTER(ARState), C.POINTER(SampleParams), c_int, c_void_p, c_int, c_void_p]),
 }
 
 

@@ -1,6 +1,7 @@
 // Model-level orchestration: one dense pass (Base.forward, models/base.py:1184-1278) and the
 // KV-cache AR decode loop (models/ar_nar.py:748-848).  Host code only enqueues kernels.
 #include "common.h"
+#include <mutex>
 
 extern "C" int valle_attn_prefill(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int M, int max_T,
                                   int H, int Dh, int causal, int dtype, void* stream) {
@@ -310,4 +311,43 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
                                int n_steps, float* logits_out, int ld_logits,
                                void* workspace, size_t workspace_bytes, void* stream) {
     return ar_decode_impl(m, st, sp, n_steps, logits_out, ld_logits, workspace, workspace_bytes, stream);
+}
+
+// ------------------------------------------------------------------ decode without a caller workspace
+// valle_ar_decode_noalloc: valle_ar_decode with the step's activations in a static device array instead of a caller
+// workspace, for callers that cannot allocate (HIP graph capture, serving loops that forbid hipMalloc).  Nothing here
+// allocates: the array lives in the code object (each GPU the library runs on holds its own copy until the process ends).
+#define VALLE_NOALLOC_SCRATCH_BYTES (2u << 20)
+static __device__ __align__(256) unsigned char scratch[VALLE_NOALLOC_SCRATCH_BYTES];
+#define VALLE_MAX_DEVICES 64
+static void* g_scratch_ptr[VALLE_MAX_DEVICES];       // per device: the device address of that GPU's copy of `scratch`
+static std::mutex g_scratch_mu;
+
+extern "C" size_t valle_noalloc_scratch_bytes(void) { return VALLE_NOALLOC_SCRATCH_BYTES; }
+
+extern "C" int valle_ar_decode_noalloc(valle_model* m, const valle_ar_state* st, const valle_sample_params* sp,
+                                       int n_steps, float* logits_out, int ld_logits, void* stream) {
+    VALLE_REQUIRE(m && st, VALLE_E_ARG, "valle_ar_decode_noalloc: null pointer");
+    VALLE_REQUIRE(st->B > 0, VALLE_E_ARG, "valle_ar_decode_noalloc: empty batch");
+    const size_t need = valle_decode_workspace_bytes(m, st->B);
+    VALLE_REQUIRE(need <= VALLE_NOALLOC_SCRATCH_BYTES, VALLE_E_WORKSPACE,
+                  "valle_ar_decode_noalloc: %d utterances at d_model %d need %zu B of scratch, the static array holds %u B; "
+                  "use valle_ar_decode with a caller workspace", st->B, m->cfg.d_model, need, VALLE_NOALLOC_SCRATCH_BYTES);
+    int dev = -1;
+    VALLE_HIP_CHECK(hipGetDevice(&dev));
+    VALLE_REQUIRE(dev >= 0 && dev < VALLE_MAX_DEVICES, VALLE_E_UNSUPPORTED, "valle_ar_decode_noalloc: device %d", dev);
+    void* ptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        if (!g_scratch_ptr[dev]) {          // once per device, with that device current: the array's address ON THIS GPU
+            void* p = nullptr;
+            VALLE_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            VALLE_REQUIRE(p != nullptr, VALLE_E_HIP, "valle_ar_decode_noalloc: no device address for the scratch array");
+            g_scratch_ptr[dev] = p;
+        }
+        ptr = g_scratch_ptr[dev];
+    }
+    // every byte of the workspace that a step reads was written earlier in the same step (or by the previous step's
+    // sampler), so nothing has to be cleared; calls that overlap on one GPU share the array and race
+    return ar_decode_impl(m, st, sp, n_steps, logits_out, ld_logits, ptr, VALLE_NOALLOC_SCRATCH_BYTES, stream);
 }

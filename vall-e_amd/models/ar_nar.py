@@ -146,6 +146,7 @@ class AR_NAR(Base):
         max_duration = kw.get("max_duration", 500)
         step_chunk = int(kw.pop("step_chunk", 32))
         return_logits = kw.pop("return_logits", False)
+        noalloc = kw.pop("noalloc", False)  # decode chunks through valle_ar_decode_noalloc (the library's static scratch array)
         prof = kw.pop("profile", None)      # list: receives (start_event, end_event, n_steps, ctx_len_host) per decode chunk
         prefix_context = kw.get("prefix_context", None)
         input_prompt_prefix = kw.pop("input_prompt_prefix", False)
@@ -246,8 +247,11 @@ class AR_NAR(Base):
                 if prof is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                L.check(lib.valle_ar_decode(self._handle, C.byref(st), C.byref(sp), n, L.ptr(lg_out), ld,
-                                            L.ptr(ws), ws.numel(), stream))
+                if noalloc:
+                    L.check(lib.valle_ar_decode_noalloc(self._handle, C.byref(st), C.byref(sp), n, L.ptr(lg_out), ld, stream))
+                else:
+                    L.check(lib.valle_ar_decode(self._handle, C.byref(st), C.byref(sp), n, L.ptr(lg_out), ld,
+                                                L.ptr(ws), ws.numel(), stream))
                 if prof is not None:
                     e1.record()
                     prof.append((e0, e1, n, [int(t) + done for t in plan.lens]))
