@@ -10,8 +10,10 @@ every implementation generates exactly R frames.
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: utterances shard by rank (one independent batch of 16 per GPU, weak scaling); the only
-collective is an RCCL all-gather of the generated codes and per-rank timings.
+Multi-GPU: utterances shard by rank -- one independent batch of 16 per GPU (weak scaling, the default) or a
+fixed global batch dealt to the ranks (--global-batch 128: strong scaling, BASELINE configs[3]); the only
+collectives are an RCCL all-gather of the generated codes and one of the per-rank timings.  Without a launcher
+`--gpus N` spawns the N ranks itself.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -58,8 +60,10 @@ def dense_pass_flops(cfg, lens, out_rows, vocab):
 
 
 def cpu_baseline(cfg, sd, phns, proms, langs, R):
-    """The oracle (CPU restatement of the reference, fp32, no KV cache like the reference) timed
-    on this box's host cores on a bounded sample; extrapolated linearly in context."""
+    """The oracle (CPU restatement of the reference, fp32) timed on this box's host cores on a bounded sample.
+    `value` = recompute mode (no KV cache: what the reference does, base.py:521), median of three samples, each the
+    line through one AR step at the first and one at the middle context summed over R steps + 7 NAR levels;
+    `cache_mode_value` = the oracle's KV-cache mode (prefill + cached steps)."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import valle_oracle as vo
     cores = min(16, os.cpu_count() or 1)
@@ -69,18 +73,16 @@ def cpu_baseline(cfg, sd, phns, proms, langs, R):
     empty = [torch.zeros(0, dtype=torch.int64) for _ in range(B)]
     plans = o._plans(phns, langs, proms, empty, 0)
     ctx0 = plans[0].pos.shape[0]
-    def time_ar(plans_, n):
+
+    def time_ar(plans_):
         t0 = time.perf_counter()
         with torch.inference_mode():
-            for _ in range(n):
-                o.forward(plans_, rows=[1] * B)
-        return (time.perf_counter() - t0) / n
+            o.forward(plans_, rows=[1] * B)
+        return time.perf_counter() - t0
 
     g = torch.Generator().manual_seed(3)
-    n_ar0, n_ar1 = 3, 2                                        # steps timed at the first and at the middle context
-    t_ar0 = time_ar(plans, n_ar0)
     half = [torch.randint(0, 1024, (R // 2,), generator=g) for _ in range(B)]
-    t_ar1 = time_ar(o._plans(phns, langs, proms, half, 0), n_ar1)
+    plans_half = o._plans(phns, langs, proms, half, 0)
     Bn = 8                                                     # one NAR level on half the batch
     resp = [torch.randint(0, 1024, (R, 1), generator=g) for _ in range(Bn)]
     nplans = o._plans(phns[:Bn], langs[:Bn], proms[:Bn], resp, 1)
@@ -88,17 +90,66 @@ def cpu_baseline(cfg, sd, phns, proms, langs, R):
     with torch.inference_mode():
         o.forward(nplans, rows=[R] * Bn)
     t_nar = (time.perf_counter() - t0) * (B / Bn)
-    # recompute AR: step n costs t(ctx0 + n), a line through the two measured contexts
-    slope = (t_ar1 - t_ar0) / (R // 2)
-    ar_total = sum(t_ar0 + slope * n for n in range(R))
-    total = ar_total + 7 * t_nar
+    time_ar(plans)                                             # warm the allocator / thread pool
+    samples, points = [], []
+    for _ in range(3):
+        t_ar0, t_ar1 = time_ar(plans), time_ar(plans_half)
+        slope = (t_ar1 - t_ar0) / (R // 2)                     # recompute AR: step n costs t(ctx0 + n)
+        total = sum(t_ar0 + slope * n for n in range(R)) + 7 * t_nar
+        samples.append(B * R / total)
+        points.append((t_ar0, t_ar1))
+    samples.sort()
+    # KV-cache mode: prefill + n cached steps, per-step cost taken at the start of the response
+    n_c = 6
+    with torch.inference_mode():
+        t0 = time.perf_counter()
+        o.ar(phns, proms, langs, max_duration=1, use_cache=True, temperature=0.0)
+        t_prefill = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        o.ar(phns, proms, langs, max_duration=1 + n_c, use_cache=True, temperature=0.0)
+        t_step = max(time.perf_counter() - t0 - t_prefill, 1e-9) / n_c
+    cache_total = t_prefill + (R - 1) * t_step + 7 * t_nar
     return {
-        "value": round(B * R / total, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-        "sample": (f"oracle (fp32 restatement, full recompute per AR step as the reference does): {n_ar0} AR steps "
-                   f"at ctx {ctx0} B={B} = {t_ar0:.2f} s/step and {n_ar1} at ctx {ctx0 + R // 2} = {t_ar1:.2f} s/step, one NAR "
-                   f"level at T={ctx0 + R} on {Bn}/{B} of the batch = {t_nar:.2f} s/level scaled; whole job = the line through "
-                   f"the two AR points summed over {R} steps + 7 NAR levels = {total:.0f} s"),
+        "value": round(samples[1], 3), "unit": "frames/s", "cores": cores, "kind": "port",
+        "spread": [round(samples[0], 3), round(samples[2], 3)],
+        "cache_mode_value": round(B * R / cache_total, 3),
+        "sample": (f"oracle (fp32 restatement of the reference), {cores} threads.  Recompute mode (no KV cache, as the reference runs): "
+                   f"3 samples of one AR step at ctx {ctx0} (" + "/".join(f"{a:.2f}" for a, _ in points) + f" s) and one at ctx {ctx0 + R // 2} ("
+                   + "/".join(f"{b:.2f}" for _, b in points) + f" s), B={B}; one NAR level at T={ctx0 + R} on {Bn}/{B} of the batch = {t_nar:.2f} s/level "
+                   f"scaled; job = line through the two AR points summed over {R} steps + 7 NAR levels; value = median, spread = min/max.  "
+                   f"Cache mode: prefill {t_prefill:.2f} s + {R - 1} x {t_step * 1e3:.0f} ms/step (mean of {n_c} cached steps at the start of the "
+                   f"response) + the same NAR levels = {cache_total:.0f} s"),
     }
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: N fresh child ranks, started before this process makes any GPU
+    call (children are new processes, never a re-exec of one that touched the GPU).  RCCL when the box has N devices;
+    otherwise the ranks share devices and rendezvous over gloo (rehearsal of the multi-rank path)."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if ndev < n:
+        env.setdefault("VALLE_BENCH_BACKEND", "gloo")
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, "-u", str(Path(__file__).resolve()), *argv],
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r))))
+    rc = 0
+    try:
+        for p_ in procs:
+            rc = max(rc, abs(p_.wait()))
+            if rc:
+                break
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+    return rc
 
 
 def main():
@@ -106,52 +157,86 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=16, help="utterances per GPU (weak scaling, the default)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="fixed total number of utterances, sharded over the ranks (strong scaling, BASELINE configs[3]: 128)")
     ap.add_argument("--frames", type=int, default=450)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-codes", default="", help="(tests) rank 0 writes every utterance's codes, in global order, to this .npy")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm; VALLE_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs
         # than ranks (ranks then share devices: local_rank % device_count)
-        dist.init_process_group(os.environ.get("VALLE_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        backend = os.environ.get("VALLE_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     cfg = vcfg.repo_default_model()
-    B, R = args.batch, args.frames
+    R = args.frames
     sd = synth_state_dict(cfg, 1234, stop_bias=-30000.0)
     model = get_model(cfg).load_state_dict(sd).to(dev, torch.bfloat16)
-    phns, proms, langs = synth_batch(1234 + rank, B, n_phn=80, n_prom=225)
-    tasks = ["tts"] * B
+    if args.global_batch > 0:
+        # strong scaling: one global list, length-sorted and dealt round-robin to the ranks as TTS.batched_inference's
+        # sharded form does (vall_e_amd.inference.shard_utterances; reference sort key inference.py:288-293)
+        from vall_e_amd.inference import shard_utterances, sort_key
+        G = args.global_batch
+        gp, gr, gl = synth_batch(1234, G, n_phn=80, n_prom=225)
+        mine = shard_utterances([sort_key(a, b) for a, b in zip(gp, gr)], world)[rank]
+        phns, proms, langs = [gp[i] for i in mine], [gr[i] for i in mine], [gl[i] for i in mine]
+        total_utts, scaling = G, "strong"
+        mode = f"configs[3]: global batch {G} sharded over {world} GPU(s) ({len(mine)} utterances on rank 0)"
+    else:
+        phns, proms, langs = synth_batch(1234 + rank, args.batch, n_phn=80, n_prom=225)
+        total_utts, scaling = world * args.batch, "weak"
+        mode = f"configs[1]: batch {args.batch}/GPU"
+    B = len(phns)
+    # a rank's utterances run in chunks of at most 32 (the decode kernels' batch; cfg.inference.batch_size plays this
+    # role in the reference, inference.py:296-311)
+    chunks = [list(range(i, min(i + 32, B))) for i in range(0, B, 32)]
     prof, nar_prof = [], []
 
     def step(profile=None):
-        codes = model(task_list=tasks, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=R,
-                      temperature=0.0, step_chunk=R, profile=profile)
-        if profile is not None:
-            n0, n1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            n0.record()
-        full = model(task_list=tasks, phns_list=phns, proms_list=proms, lang_list=langs,
-                     resps_list=codes, temperature=0.0)
-        if profile is not None:
-            n1.record()
-            nar_prof.append((n0, n1))
-        out = torch.stack([f.to(torch.int16) for f in full])            # (B, R, 8)
+        outs = []
+        for ch in chunks:
+            kw = dict(task_list=["tts"] * len(ch), phns_list=[phns[i] for i in ch], proms_list=[proms[i] for i in ch],
+                      lang_list=[langs[i] for i in ch])
+            codes = model(**kw, max_duration=R, temperature=0.0, step_chunk=R, profile=profile)
+            if profile is not None:
+                n0, n1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n0.record()
+            full = model(**kw, resps_list=codes, temperature=0.0)
+            if profile is not None:
+                n1.record()
+                nar_prof.append((n0, n1))
+            outs.extend(full)
+        out = torch.stack([f.to(torch.int16) for f in outs])            # (B, R, 8)
         if dist is not None:
             raw = out.view(torch.uint8)                                 # RCCL has no int16: ship the bytes
-            if dist.get_backend() == "gloo":                            # the CPU rehearsal backend gathers host tensors
+            if backend == "gloo":                                       # the CPU rehearsal backend gathers host tensors
                 raw = raw.cpu()
+            if args.global_batch > 0 and B * world != total_utts:       # ragged shards: pad to the largest
+                pad = (total_utts + world - 1) // world - B
+                raw = torch.cat([raw, raw.new_zeros((pad,) + tuple(raw.shape[1:]))]) if pad else raw
             gathered = [torch.empty_like(raw) for _ in range(world)]
             dist.all_gather(gathered, raw)                              # RCCL: codes of every rank
             assert all(g.shape == raw.shape for g in gathered)
+            step.gathered = [g.cpu().view(torch.int16) for g in gathered]
+        else:
+            step.gathered = [out.cpu()]
         return out
 
     def fence():
@@ -162,19 +247,23 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
-    assert out.shape == (B, R, 8), out.shape
+    if args.warmup:
+        assert out.shape == (B, R, 8), out.shape
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(profile=prof)
     fence()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    rank_seconds = [elapsed]
+    if dist is not None:                                                # every rank's time; the job's time is the slowest rank's
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else dev)
+        ts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(ts, t)
+        rank_seconds = [float(x.item()) for x in ts]
+        elapsed = max(rank_seconds)
 
-    frames = world * B * R * args.steps
+    frames = total_utts * R * args.steps
     ms_per_step = elapsed / args.steps * 1e3
     # roofline of the dominant kernel group: the AR decode step (weights + KV cache streamed once)
     dec_ms, dec_steps, dec_bytes = 0.0, 0, 0.0
@@ -182,10 +271,10 @@ def main():
         dec_ms += e0.elapsed_time(e1)
         dec_steps += n
         for j in range(n):
-            dec_bytes += decode_step_bytes(cfg, B, [c + j for c in ctx0])
+            dec_bytes += decode_step_bytes(cfg, len(ctx0), [c + j for c in ctx0])
     roofline = None
     traffic, traffic_src = None, None
-    pmc = ROOT / "profiles" / "r1_pmc_decode_layer.json"
+    pmc = ROOT / "profiles" / "r2_pmc_decode_layer.json"
     if dec_steps and pmc.exists():
         # HBM bytes per decode step from the PMC passes committed under profiles/ (FETCH_SIZE x2 on gfx950 +
         # WRITE_SIZE, collected on the same kernels at the bench's mean context): measured / algorithmic of one
@@ -202,30 +291,45 @@ def main():
                     "algorithmic_bytes_per_step": int(dec_bytes / dec_steps)}
     dense = None
     if nar_prof:
-        T = int(phns[0].shape[0]) + int(proms[0].shape[0]) + R + 6
-        fl = 7 * dense_pass_flops(cfg, [T] * B, B * R, cfg.audio_tokens)
-        nar_ms = sum(a.elapsed_time(b) for a, b in nar_prof) / len(nar_prof)
+        lens = [int(p.shape[0]) + int(q.shape[0]) + R + 6 for p, q in zip(phns, proms)]
+        fl = 7 * dense_pass_flops(cfg, lens, B * R, cfg.audio_tokens)
+        nar_ms = sum(a.elapsed_time(b) for a, b in nar_prof) / args.steps      # all chunks of a step
         tf = fl / (nar_ms * 1e-3) / 1e12
         dense = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                 "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "what": f"7 NAR levels, {B} x {T} tokens each, host time included",
+                 "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "what": f"7 NAR levels, {B} x {lens[0]} tokens each, host time included",
                  "ms": round(nar_ms, 2)}
-        mf = ROOT / "profiles" / "r1_pmc_mfma_dense_gemms.json"
+        mf = ROOT / "profiles" / "r2_pmc_mfma_dense_gemms.json"
+        if not mf.exists():
+            mf = ROOT / "profiles" / "r1_pmc_mfma_dense_gemms.json"
         if mf.exists():     # MFMA pipe utilisation of the four layer GEMMs from the PMC pass committed under profiles/
             dense["mfma_busy_frac_pmc"] = {k.split("(")[0].replace("void ", ""): round(v["mfma_busy_frac"], 3)
                                            for k, v in json.loads(mf.read_text()).items()}
             dense["mfma_busy_source"] = f"profiles/{mf.name} (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 256 CUs x 4 SIMDs), tools/micro_gemm)"
+    if rank == 0 and args.dump_codes:
+        # utterance i of the job: weak mode = rank-major; strong mode = the shard lists
+        if args.global_batch > 0:
+            shards = shard_utterances([sort_key(a, b) for a, b in zip(gp, gr)], world)
+            allc = np.zeros((total_utts, R, 8), dtype=np.int16)
+            for r_, idx in enumerate(shards):
+                allc[idx] = step.gathered[r_][: len(idx)].numpy()
+        else:
+            allc = np.concatenate([g.numpy() for g in step.gathered])
+        np.save(args.dump_codes, allc)
     if rank == 0:
         line = {
             "metric": "RVQ frames/sec (all levels)", "value": round(frames / elapsed, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[1]: AR KV-cache decode + 7 NAR levels, repo-default ar+nar llama (d=1024, L=12), "
-                                   f"batch {B}/GPU, 80 phonemes, 225 prompt frames, {R} output frames, greedy",
-                       "global_batch": world * B, "frames_per_utterance": R, "parallelism": f"utterance-sharded x{world}"},
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{mode}: AR KV-cache decode + 7 NAR levels, repo-default ar+nar llama (d=1024, L=12), "
+                                   f"80 phonemes, 225 prompt frames, {R} output frames, greedy",
+                       "global_batch": total_utts, "frames_per_utterance": R, "parallelism": f"utterance-sharded x{world}"},
             "rtf": round((elapsed / args.steps) / (R / FRAME_RATE), 5),
+            "rank_seconds": [round(x, 4) for x in rank_seconds],
             "roofline": roofline,
             "dense": dense,
         }
+        if backend is not None:
+            line["collective_backend"] = "rccl" if backend == "nccl" else f"{backend} (ranks share devices: rehearsal, not a scaling number)"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, phns, proms, langs, R)
         print(json.dumps(line), flush=True)
