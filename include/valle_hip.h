@@ -132,7 +132,8 @@ typedef struct {
     double dry_multiplier;
     double dry_base;
     int    dry_allowed_length;      /* >= 2 makes the reference's loop a no-op; kept for fidelity   */
-    int    reserved;
+    int    filter_passes;           /* 0 / 1: top-k / top-p once; 2 reproduces NAR-len's second in-place pass
+                                     * (only when min_p is off: min-p filters out of place, samplers.py:90)   */
 } valle_sample_params;
 
 /* Sampler chain on fp32 logits [rows][ld] (first `vocab` columns valid): repetition penalty

@@ -476,6 +476,42 @@ def scen_tiny_narlen():
         raise RuntimeError("tiny_narlen_masked_only: no inputs where the option matters")
 
 
+def scen_tiny_narlen_topp():
+    """NAR-len with top_p < 1: the second ("unfiltered") sample call of ar_nar.py:447-453 runs on logits the first call has
+    already filtered in place (samplers.py:93-125), so top-p acts twice before the scores are taken.  The per-step scores
+    stored here differ from those of a single application (checked below: the golden pins the double application); the
+    final codes did not differ for any of 330 searched inputs, so the tests compare the scores step by step."""
+    ref = rh.load_reference()
+    model, _ = get_ref_model("tiny")
+    sam_base = ref.models.base
+    orig = sam_base.top_k_top_p_filtering
+    pure = lambda logits, **k: orig(logits.clone(), **k)              # out-of-place variant: what a single application gives
+    for seed in range(71, 111):
+        phns, proms, langs = synth_batch(seed, 2, n_phn=10, n_prom=16, ragged=True)
+        try:
+            narlen_scenario("tiny_narlen_topp", "tiny", phns, proms, langs, lens=[18, 25], max_steps=6, top_p=0.5, top_no=0.0)
+        except RuntimeError as e:
+            print("  ", e)
+            continue
+        z = dict(np.load(GOLD / "tiny_narlen_topp.npz"))
+        base = sam_base.Base
+        orig_sample, got = base.sample, []
+
+        def wrapped(self_, *a, **k):
+            out = orig_sample(self_, *a, **k)
+            got.append([s_.clone() for s_ in out.scores])
+            return out
+        base.sample, sam_base.top_k_top_p_filtering = wrapped, pure
+        try:
+            run_narlen(model, phns, proms, langs, [18, 25], max_steps=6, temperature=0.0, top_p=0.5, top_no=0.0)
+        finally:
+            base.sample, sam_base.top_k_top_p_filtering = orig_sample, orig
+        single = got[1][0].float().numpy()
+        assert np.abs(single - z["step0_scores_0"]).max() > 1e-3, "double top-p does not show in the scores"
+        return
+    raise RuntimeError("tiny_narlen_topp: every input cuts through a tie")
+
+
 def scen_tiny_len():
     """Duration prediction (task ``len``, ar_nar.py:640-692) the way inference.py:329 calls it.  Two weight
     seeds: one whose utterances stop at different steps (the loop keeps appending to stopped ones), one where
@@ -764,6 +800,7 @@ SCENARIOS = {
     "tiny_sampling": scen_tiny_sampling,
     "tiny_cfg": scen_tiny_cfg,
     "tiny_narlen": scen_tiny_narlen,
+    "tiny_narlen_topp": scen_tiny_narlen_topp,
     "tiny_len": scen_tiny_len,
     "tiny_prefix_context": scen_tiny_prefix_context,
     "tiny_noncausal": scen_tiny_noncausal,

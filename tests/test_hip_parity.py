@@ -318,6 +318,28 @@ def test_tiny_narlen_codes_identical(gpu_device):
     _narlen("tiny", "tiny_narlen_masked_only", sampling_scores_masked_only=True)      # ar_nar.py:459-460
 
 
+def test_tiny_narlen_top_p_filters_twice(gpu_device):
+    """NAR-len with top_p < 1: the reference's second sample call sees logits its first call filtered in
+    place, so top-p acts twice before the scores are taken (samplers.py:93-125, ar_nar.py:436-453).  Golden
+    tiny_narlen_topp: codes identical, and every step's ids and scores equal the reference's (the generator asserts
+    that a single application gives other scores)."""
+    z = load_golden("tiny_narlen_topp")
+    phns, proms, langs = golden_inputs(z)
+    m = hip_model("tiny")
+    lens = [int(x) for x in z["lens"]]
+    trace = []
+    full = m(task_list=["tts"] * 2, phns_list=phns, proms_list=proms, lang_list=langs, len_list=lens,
+             max_steps=int(z["max_steps"]), temperature=0.0, top_p=0.5, top_no=0.0, trace=trace)
+    for b in range(2):
+        np.testing.assert_array_equal(full[b].cpu().numpy(), z[f"codes_{b}"])
+    assert len(trace) == int(z["max_steps"])
+    for step, (ids, sc) in enumerate(trace):
+        ids, sc = ids.cpu().numpy(), sc.cpu().numpy()
+        for b, (lo, hi) in enumerate(((0, lens[0]), (lens[0], lens[0] + lens[1]))):
+            np.testing.assert_array_equal(ids[lo:hi], z[f"step{step}_ids_{b}"])
+            np.testing.assert_allclose(sc[lo:hi], z[f"step{step}_scores_{b}"], rtol=2e-4, atol=1e-7)
+
+
 def test_full_narlen_codes_identical(gpu_device):
     _narlen("full", "full_narlen")
 
@@ -823,3 +845,29 @@ def test_reference_surface_inputs_forward_super_sample(gpu_device):
         assert torch.equal(ids.cpu(), l.argmax(-1).cpu())
     ar = m.sample(a.logits, temperature=0.0, top_no=0.0)          # AR form: last row only
     assert [int(i[0]) for i in ar.ids] == [int(l[-1].argmax()) for l in a.logits]
+
+
+def test_tts_seed_reaches_the_sampler(gpu_device):
+    """`seed` of TTS.batched_inference / TTS.inference (the reference reseeds per chunk, inference.py:315, :403) drives
+    the Philox stream of every model call: the same seed reproduces the codes, another seed changes them, identical
+    inputs in different chunks draw different uniforms, and seed=None picks a fresh seed per call."""
+    from vall_e_amd.inference import TTS
+    from vall_e_amd.synth import synth_batch
+    phns, proms, langs = synth_batch(5, 1, n_phn=12, n_prom=20)
+    phns, proms, langs = phns * 4, proms * 4, langs * 4                   # four copies of one utterance
+    tts = TTS(config=model_cfg("tiny"), device="cuda:0", dtype=torch.float32, state_dict=synth_weights("tiny"))
+    kw = dict(batch_size=2, max_duration=12, temperature=1.0, top_no=0.0)
+    run = lambda **k: [c[:, 0].cpu().numpy() for c in tts.batched_inference(list(phns), list(proms), list(langs), **kw, **k)]
+    a, b, c = run(seed=7), run(seed=7), run(seed=8)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    assert any(x.shape != y.shape or (x != y).any() for x, y in zip(a, c))
+    # copies 0/1 sit in chunk 0, copies 2/3 in chunk 1: same inputs, same row index, different chunk -> different draws
+    assert a[0].shape != a[2].shape or (a[0] != a[2]).any()
+    d, e = run(), run()                                                   # seed=None
+    assert any(x.shape != y.shape or (x != y).any() for x, y in zip(d, e))
+    l1 = tts.inference([phns[0]], proms[0], language=langs[0], max_duration=12, temperature=1.0, top_no=0.0, seed=3)
+    l2 = tts.inference([phns[0]], proms[0], language=langs[0], max_duration=12, temperature=1.0, top_no=0.0, seed=3)
+    l3 = tts.inference([phns[0]], proms[0], language=langs[0], max_duration=12, temperature=1.0, top_no=0.0, seed=4)
+    np.testing.assert_array_equal(l1[0].cpu().numpy(), l2[0].cpu().numpy())
+    assert l1[0].shape != l3[0].shape or (l1[0] != l3[0]).any()

@@ -303,3 +303,28 @@ def test_sequences_beyond_the_rope_table_are_refused():
     phn = torch.zeros(70, dtype=torch.uint8)
     with pytest.raises(ValueError, match="max_position_embeddings"):
         m.plan([phn], [torch.tensor([0], dtype=torch.uint8)], [None], [torch.zeros(0, dtype=torch.int64)], 0)
+
+
+def test_derive_seed_separates_chunks_ranks_and_phases():
+    from vall_e_amd.inference import derive_seed
+    seen = {derive_seed(5, c, r, ph) for c in range(8) for r in range(8) for ph in range(2)}
+    assert len(seen) == 128 and all(0 <= s < 2 ** 63 for s in seen)
+    assert derive_seed(5, 1, 0, 0) == derive_seed(5, 1, 0, 0) != derive_seed(6, 1, 0, 0)
+    assert derive_seed(None) != derive_seed(None)
+
+
+def test_from_dict_refuses_unbuilt_experimental_switches():
+    """A checkpoint's metadata that sets a switch the HIP path does not implement must not load silently."""
+    from vall_e_amd.config import Model
+    ok = Model.from_dict({"size": "full", "experimental": {"audio_embedding_sums": True, "rvq_levels_p": "equal", "layerskip_r": 2,
+                                                           "kv_heads": 0, "tie_classifier_to_embedding": False}})
+    assert ok.experimental.audio_embedding_sums is True
+    for bad in ({"tie_classifier_to_embedding": True}, {"interleave": True}, {"hf": True}, {"audio_embedding_mode": "inclusive"},
+                {"logit_normalization": 1.0}, {"use_sliding_attention_mask": True}):
+        with pytest.raises(NotImplementedError):
+            Model.from_dict({"size": "full", "experimental": bad})
+    with pytest.raises(NotImplementedError):
+        Model.from_dict({"size": {"dim": 1024, "heads": 16, "layers": 12}, "experimental": {"kv_heads": 4}})
+    with pytest.raises(NotImplementedError):
+        Model.from_dict({"size": {"dim": 1024, "heads": 16, "layers": 12, "embed_dim": 512}})
+    Model.from_dict({"size": {"dim": 1024, "heads": 16, "layers": 12, "embed_dim": 1024}, "experimental": {"kv_heads": 16}})

@@ -184,6 +184,7 @@ def _narlen(kind, name, **kw):
 
 def test_tiny_narlen():
     _narlen("tiny", "tiny_narlen")
+    _narlen("tiny", "tiny_narlen_topp", top_p=0.5, top_no=0.0)     # top-p acts twice before the scores (in-place filter)
     _narlen("tiny", "tiny_narlen_masked_only", sampling_scores_masked_only=True)      # ar_nar.py:459-460
     z = load_golden("tiny_narlen_masked_only")                 # inputs were searched so that the option matters
     phns, proms, langs = golden_inputs(z)

@@ -28,7 +28,7 @@ class SampleParams(C.Structure):
         ("length_penalty", C.c_float), ("stop_token", C.c_int), ("rep_pen_passes", C.c_int),
         ("seed", C.c_uint64), ("offset", C.c_uint64),
         ("temperature64", C.c_double), ("min_temperature64", C.c_double),
-        ("dry_multiplier", C.c_double), ("dry_base", C.c_double), ("dry_allowed_length", C.c_int), ("reserved", C.c_int),
+        ("dry_multiplier", C.c_double), ("dry_base", C.c_double), ("dry_allowed_length", C.c_int), ("filter_passes", C.c_int),
     ]
 
 

@@ -101,6 +101,21 @@ class Model:
             exp_obj = exp
         else:
             known = {f.name for f in fields(ModelExperimentalSettings)}
+            # switches of the reference (config.py:268-354) that change what the forward computes and are not built here:
+            # a checkpoint that sets one must not load and silently run with other semantics.  Everything else that is
+            # dropped below only steers training (loss factors, dropout odds, level sampling).
+            probe = cls(size=d.get("size", "full"))
+            dim, heads = probe.dim, probe.heads
+            unbuilt = {"hf": False, "interleave": False, "audio_embedding_mode": None, "tie_classifier_to_embedding": False,
+                       "monolithic_audio_encoder": False, "logit_normalization": 0, "use_segmented_attention_mask": False,
+                       "use_sliding_attention_mask": False, "predict_causally": False}
+            for k, off in unbuilt.items():
+                if k in exp and exp[k] != off and exp[k]:
+                    raise NotImplementedError(f"experimental.{k}={exp[k]!r} is not built on the HIP path")
+            if exp.get("kv_heads", 0) not in (0, heads, None):
+                raise NotImplementedError(f"experimental.kv_heads={exp['kv_heads']}: grouped-query attention is not built (MHA only)")
+            if isinstance(d.get("size"), dict) and d["size"].get("embed_dim", dim) != dim:
+                raise NotImplementedError(f"size.embed_dim={d['size']['embed_dim']} != dim: separate embedding width is not built")
             exp_obj = ModelExperimentalSettings(**{k: v for k, v in exp.items() if k in known})
         known = {f.name for f in fields(cls)} - {"experimental"}
         return cls(experimental=exp_obj, **{k: v for k, v in d.items() if k in known})

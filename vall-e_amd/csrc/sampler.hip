@@ -197,7 +197,9 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
     }
     // ---- top-k (samplers.py:102-106): keep logits >= the k-th largest value (ties kept); top-p (:108-123): softmax of
     // what is left, drop a column when the mass ranked before it exceeds top_p (the first column always stays)
-    if (a.p.top_k > 0 || a.p.top_p < 1.0f) {
+    // filter_passes = 2 replays the reference's in-place filter for NAR-len's second sample call (ar_nar.py:447-453 samples
+    // twice on the same tensors; top-p on the already filtered, renormalised row can drop more columns)
+    for (int fpass = 0; fpass < (a.p.filter_passes > 1 ? a.p.filter_passes : 1) && (a.p.top_k > 0 || a.p.top_p < 1.0f); ++fpass) {
         float mx = -INFINITY;
         for (int v = tid; v < V; v += SAMP_THREADS) mx = fmaxf(mx, vals[v]);
         mx = block_reduce_max(mx, red);
@@ -489,6 +491,7 @@ extern "C" int valle_sample(const float* logits, int ld, int vocab, int rows, co
     VALLE_REQUIRE(vocab > 1 && vocab <= SAMP_MAXV && ld >= vocab, VALLE_E_ARG, "valle_sample: vocab %d (max %d), ld %d", vocab, SAMP_MAXV, ld);
     VALLE_REQUIRE(prev == nullptr || (prev_off && prev_len), VALLE_E_ARG, "valle_sample: prev needs prev_off/prev_len");
     VALLE_REQUIRE(params->rep_pen_passes >= 1 && params->rep_pen_passes <= 2, VALLE_E_ARG, "valle_sample: rep_pen_passes must be 1 or 2");
+    VALLE_REQUIRE(params->filter_passes >= 0 && params->filter_passes <= 2, VALLE_E_ARG, "valle_sample: filter_passes must be 0, 1 or 2");
     if (rows == 0) return VALLE_OK;
     SampleArgs a{};
     a.logits = logits; a.ld = ld; a.vocab = vocab; a.row_item = row_item; a.row_in_item = row_in_item;

@@ -35,6 +35,20 @@ def shard_utterances(lengths, world_size):
     return [order[r::world_size] for r in range(world_size)]
 
 
+def derive_seed(seed, *parts):
+    """One Philox seed per model call from (user seed, chunk or line index, rank, phase): the reference reseeds torch per
+    batch (``set_seed(seed)``, inference.py:315, :403) and picks a random seed when none is given; a counter-based generator
+    needs distinct seeds instead, or every chunk, rank and phase would draw the same uniforms.  splitmix64 over the parts."""
+    import os
+    x = int(seed) & 0xFFFFFFFFFFFFFFFF if seed is not None else int.from_bytes(os.urandom(8), "little")
+    for p in parts:
+        x = (x + 0x9E3779B97F4A7C15 + (int(p) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        x ^= x >> 31
+    return x & 0x7FFFFFFFFFFFFFFF
+
+
 def chunk(indices, batch_size):
     """inference.py:296-311."""
     batch_size = max(1, int(batch_size))
@@ -162,7 +176,10 @@ class TTS:
         a list (one value per line)."""
         if task not in ("tts", "ns", "sr"):
             raise NotImplementedError(f"task {task!r}: TTS.inference is built for 'tts', 'ns' and 'sr'")
-        for k in ("input_prompt_length", "seed", "tqdm", "use_lora", "dtype", "amp", "voice_convert", "split_text_by"):
+        seed = sampling_kwargs.pop("seed", None)              # None: a fresh one per call, as the reference does
+        if seed is None:
+            seed = derive_seed(None)
+        for k in ("input_prompt_length", "tqdm", "use_lora", "dtype", "amp", "voice_convert", "split_text_by"):
             sampling_kwargs.pop(k, None)
         phonemize = sampling_kwargs.pop("phonemize", True)     # False: lines are raw-text ids, sent as text_list (inference.py:518-519)
         modality = self.modality(sampling_kwargs.pop("modality", "auto"))
@@ -196,11 +213,11 @@ class TTS:
                     lens = [int(max(l, 75) * duration_padding) for l in lens]     # inference.py:535-538 (75 frames per second)
                 if prefix_context is not None:
                     per_line["prefix_context"] = prefix_context
-                resps = self.model(**kw, task_list=["tts"], len_list=lens, **per_line)
+                resps = self.model(**kw, task_list=["tts"], len_list=lens, seed=derive_seed(seed, n, 0, 1), **per_line)
             else:
                 extra = {"prefix_context": prefix_context} if prefix_context is not None else {}
-                resps = self.model(**kw, task_list=["tts"], **per_line, **extra)
-                resps = self.model(**kw, task_list=["tts"], resps_list=resps, **per_line)
+                resps = self.model(**kw, task_list=["tts"], seed=derive_seed(seed, n, 0, 0), **per_line, **extra)
+                resps = self.model(**kw, task_list=["tts"], resps_list=resps, seed=derive_seed(seed, n, 0, 1), **per_line)
             r = resps[0]
             out.append(r)
             if context_history > 0:                                               # inference.py:575-584
@@ -217,7 +234,10 @@ class TTS:
         world_size > 1 (use ``gather_codes`` to assemble), else the full list in input order."""
         batch_size = sampling_kwargs.pop("batch_size", self.batch_size)
         modality = self.modality(sampling_kwargs.pop("modality", "auto"))
-        for k in ("input_prompt_length", "seed", "tqdm", "use_lora", "dtype", "amp"):
+        seed = sampling_kwargs.pop("seed", None)              # inference.py:315: set_seed per chunk; None = a fresh seed
+        if seed is None:
+            seed = derive_seed(None)
+        for k in ("input_prompt_length", "tqdm", "use_lora", "dtype", "amp"):
             sampling_kwargs.pop(k, None)
         duration_padding = sampling_kwargs.pop("duration_padding", 1.05)
         n = len(texts)
@@ -229,7 +249,7 @@ class TTS:
         lengths = [sort_key(t, r) for t, r in zip(texts, references)]
         mine = shard_utterances(lengths, world_size)[rank]
         results = {}
-        for idx in chunk(mine, batch_size):
+        for ci, idx in enumerate(chunk(mine, batch_size)):
             kw = dict(task_list=["tts"] * len(idx), phns_list=[texts[i] for i in idx],
                       proms_list=[references[i] for i in idx], lang_list=[languages[i] for i in idx])
             if modality == "nar-len":
@@ -238,10 +258,10 @@ class TTS:
                 else:                                                            # inference.py:328-332
                     lens = self.model(**{**kw, "task_list": ["len"] * len(idx)}, max_duration=5)
                     lens = [int(l * duration_padding) for l in lens]
-                resps = self.model(**kw, len_list=lens, **sampling_kwargs)
+                resps = self.model(**kw, len_list=lens, seed=derive_seed(seed, ci, rank, 1), **sampling_kwargs)
             else:
-                resps = self.model(**kw, **sampling_kwargs)
-                resps = self.model(**kw, resps_list=resps, **sampling_kwargs)
+                resps = self.model(**kw, seed=derive_seed(seed, ci, rank, 0), **sampling_kwargs)
+                resps = self.model(**kw, resps_list=resps, seed=derive_seed(seed, ci, rank, 1), **sampling_kwargs)
             for i, r in zip(idx, resps):
                 results[i] = r
         if world_size == 1:

@@ -501,6 +501,7 @@ class AR_NAR(Base):
         remasking = kw.get("sampling_scores_remask", False)
         prefix_context = kw.pop("prefix_context", None)
         masked_only = kw.pop("sampling_scores_masked_only", False)
+        trace = kw.pop("trace", None)          # list: receives (ids, scores) of every demasking step, packed rows (tests)
         if kw.get("vc_list") is not None:
             raise NotImplementedError("vc_list is not built on the HIP path")
         if start_noise > 0.0:
@@ -557,10 +558,14 @@ class AR_NAR(Base):
             sp1 = self.sample_params(temperature=temp, **kw)
             sp1.offset = 2000 + step
             ids, _ = self.sample_rows(logits, V, roff, None, nar_mode=1, params=sp1, dev=sdev)
-            # the reference's second ("unfiltered") sample runs on tensors its in-place processors
-            # have already touched: the repetition penalty is applied a second time
-            sp2 = self.sample_params(temperature=0.0, rep_pen_passes=2 if kw.get("repetition_penalty", 1.0) != 1.0 else 1, **kw)
+            # the reference's second ("unfiltered") sample call runs on the tensors the first one processed in place: the
+            # repetition penalty and -- unless min-p, which filters out of place, sits in between -- top-k / top-p act twice
+            refilter = (kw.get("top_k", -100) > 0 or kw.get("top_p", 1.0) < 1.0) and kw.get("min_p", 0.0) <= 0.0
+            sp2 = self.sample_params(temperature=0.0, rep_pen_passes=2 if kw.get("repetition_penalty", 1.0) != 1.0 else 1,
+                                     filter_passes=2 if refilter else 1, **kw)
             _, sc = self.sample_rows(logits, V, roff, None, nar_mode=1, params=sp2, dev=sdev)
+            if trace is not None:
+                trace.append((ids.clone(), sc.clone()))
             codes = torch.where(is_masked.bool(), ids, codes)                  # ar_nar.py:457
             scores = torch.where(is_masked.bool(), sc, torch.ones_like(sc)) if masked_only else sc   # ar_nar.py:459-462
         codes = codes.to(torch.int16)
