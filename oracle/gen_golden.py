@@ -323,12 +323,12 @@ def scen_tiny_fwd():
 MIN_GAP = 2e-4  # greedy decisions closer than this are not a fair bit-exactness pin in fp32
 
 
-def ar_nar_scenario(name, kind, make_inputs, seed, steps, **kw):
+def ar_nar_scenario(name, kind, make_inputs, seed, steps, min_gap=None, **kw):
     """Tries input seeds seed, seed+1, ... until every greedy decision has a top-2 margin > MIN_GAP."""
     for s in range(seed, seed + 16):
         phns, proms, langs = make_inputs(s)
         d, gap = _ar_nar_scenario(name, kind, phns, proms, langs, steps, **kw)
-        if gap > MIN_GAP:
+        if gap > (MIN_GAP if min_gap is None else min_gap):
             d["input_seed"] = np.int64(s)
             save(name, **d)
             return
@@ -759,6 +759,28 @@ def scen_full_b1():
     ar_nar_scenario("full_b1", "full", lambda s: (phns, proms, langs), 0, steps=24)
 
 
+def scen_long():
+    """Realistic lengths: configs[0] -- the qnt.enc prompt, one utterance, the full model in fp32 --
+    for 160 greedy AR steps + 7 NAR levels with every step's logits kept (the test measures the HIP-vs-reference logit error
+    on all of them and asserts the smallest top-2 margin is > 10x that error), and a 320-step two-utterance tiny case for
+    the chunked KV-cache loop (step_chunk 1 / 32 / all)."""
+    phns, proms, langs = qnt_inputs()
+    for ws in (() if os.environ.get("GOLDEN_SKIP_FULL_LONG") else (WEIGHT_SEED, 4321, 777, 99)):
+        d, gap = _ar_nar_scenario("full_b1_long", "full", phns, proms, langs, 160, keep_logit_steps=160,
+                                  model_kw=dict(weight_seed=ws))
+        if gap > MIN_GAP:
+            d["weight_seed"] = np.int64(ws)
+            save("full_b1_long", **d)
+            break
+        print(f"  [full_b1_long] weight seed {ws}: min gap {gap:.2e} too small")
+    else:
+        if not os.environ.get("GOLDEN_SKIP_FULL_LONG"):
+            raise RuntimeError("full_b1_long: no weight seed with margin")
+    mk = lambda s_: synth_batch(s_, 2, n_phn=12, n_prom=20, ragged=True)
+    # 640 greedy decisions on the flat logits of the tiny model: margin bar 4e-5 (the HIP fp32 logit error there is ~1e-6)
+    ar_nar_scenario("tiny_long", "tiny", mk, 301, steps=320, min_gap=4e-5, nar=False)
+
+
 def scen_full_b3():
     mk = lambda s: synth_batch(s, 3, n_phn=30, n_prom=60, ragged=True)
     ar_nar_scenario("full_b3", "full", mk, 61, steps=12)
@@ -810,6 +832,7 @@ SCENARIOS = {
     "tiny_tone": scen_tiny_tone,
     "tiny_unified_positions": scen_tiny_unified_positions,
     "full_b1": scen_full_b1,
+    "long": scen_long,
     "full_b3": scen_full_b3,
     "full_narlen": scen_full_narlen,
     "full_bf16": scen_full_bf16,

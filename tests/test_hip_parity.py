@@ -298,6 +298,67 @@ def test_full_b1_configs0_codes_identical(gpu_device):
     _ar_nar("full", "full_b1")
 
 
+def test_full_b1_long_configs0_160_steps(gpu_device):
+    """BASELINE.json configs[0] at a realistic length: 160 greedy AR steps + 7 NAR levels on the full
+    model in fp32, KV-cache path, codes identical to the reference -- and the claim is safe: the smallest top-2 margin of
+    any of the reference's greedy decisions is more than 10x the largest HIP-vs-reference logit error over ALL 160 steps."""
+    z = load_golden("full_b1_long")
+    phns, proms, langs = golden_inputs(z)
+    m = hip_model("full", weight_seed=int(z["weight_seed"]))
+    codes, logits = m(task_list=["tts"], phns_list=phns, proms_list=proms, lang_list=langs, max_duration=int(z["steps"]),
+                      temperature=0.0, return_logits=True, step_chunk=64)
+    np.testing.assert_array_equal(codes[0].cpu().numpy(), z["ar_codes_0"])
+    got = torch.stack([l.cpu() for l in logits])[:, :, :1025]
+    err = (got.double() - torch.from_numpy(z["ar_last_logits"]).double()).abs().max().item()
+    gap = min(float(z["ar_top2_gap"].min()), float(z["nar_min_top2_gap"].min()))
+    print(f"full_b1_long: max |logit error| over 160 steps {err:.3e}, smallest top-2 margin {gap:.3e}")
+    assert gap > 10 * err, (gap, err)
+    full = m(task_list=["tts"], phns_list=phns, proms_list=proms, lang_list=langs, resps_list=[codes[0].clone()], temperature=0.0)
+    np.testing.assert_array_equal(full[0].cpu().numpy(), z["nar_codes_0"])
+
+
+@pytest.mark.parametrize("step_chunk", [1, 32, 320])
+def test_tiny_long_320_steps_chunked(gpu_device, step_chunk):
+    """320 greedy steps, two ragged utterances, through the chunked KV-cache loop at chunk sizes 1 / 32 / all: the same
+    codes as the reference whatever the chunking (margin of the golden 4.6e-5, HIP fp32 logit error asserted 10x below)."""
+    z = load_golden("tiny_long")
+    phns, proms, langs = golden_inputs(z)
+    m = hip_model("tiny")
+    codes, logits = m(task_list=["tts"] * 2, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=int(z["steps"]),
+                      temperature=0.0, return_logits=True, step_chunk=step_chunk)
+    for b in range(2):
+        np.testing.assert_array_equal(codes[b].cpu().numpy(), z[f"ar_codes_{b}"])
+    n = z["ar_last_logits"].shape[0]
+    err = (torch.stack([l.cpu() for l in logits[:n]])[:, :, :1025].double() - torch.from_numpy(z["ar_last_logits"]).double()).abs().max().item()
+    assert float(z["ar_top2_gap"].min()) > 10 * err, (float(z["ar_top2_gap"].min()), err)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_bench_shape_b16_bf16_vs_oracle(gpu_device, ragged):
+    """BASELINE.json configs[1] at its own shape: full model, bf16, 16 utterances, the bench's synthetic
+    batch (80 phonemes, 225 prompt frames; ragged: 40-120 phonemes, 150-300 frames) -- the template instances bench.py
+    times (dec_wave_kernel<.., 8, 2, ..> / <1, 2, 8, .., 4>, attn_decode_bf16_kernel<12, 8>).  Per-step logits of the
+    KV-cache decode, teacher-forced on the HIP path's own codes, against the bf16 oracle (the reference's bf16 semantics) at
+    the first steps, mid-way and at the last step: rel-L2 <= 4e-2 per step over the whole batch and per utterance <= 8e-2."""
+    from vall_e_amd.synth import synth_batch
+    import valle_oracle as vo
+    B, R = 16, (450 if not ragged else 200)
+    steps = (0, 1, 225, 449) if not ragged else (0, 1, 199)
+    phns, proms, langs = synth_batch(1234, B, n_phn=80, n_prom=225, ragged=ragged)
+    m = hip_model("full", torch.bfloat16, stop_bias=-30000.0)
+    codes, logits = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=R,
+                      temperature=0.0, return_logits=True, step_chunk=R)
+    assert all(c.shape[0] == R for c in codes)
+    o = oracle("full", torch.bfloat16, stop_bias=-30000.0)
+    for step in steps:
+        plans = [vo.plan_sequence(phns[i], langs[i], proms[i], codes[i][:step].cpu(), 0) for i in range(B)]
+        want = torch.stack([l[0].float() for l in o.forward(plans, rows=[1] * B)])[:, :1024]      # (stop logit: -30000 on both sides)
+        got = logits[step][:, :1024].float().cpu()
+        assert rel_l2(got, want) < 4e-2, (step, rel_l2(got, want))
+        worst = max(rel_l2(got[b], want[b]) for b in range(B))
+        assert worst < 8e-2, (step, worst)
+
+
 def test_full_b3_ragged_codes_identical(gpu_device):
     _ar_nar("full", "full_b3")
 

@@ -414,3 +414,15 @@ def test_full_bf16_logits_tolerance():
     ref = torch.from_numpy(z["ar_logits_last16"])
     rel = ((lg - ref).norm() / ref.norm()).item()
     assert rel < 4e-2, rel
+
+
+def test_long_sequences_oracle():
+    """Realistic lengths: the 320-step tiny case in KV-cache mode (every code) and the first 40 of the 160 steps of
+    configs[0] on the full model in recompute mode, against the reference's goldens."""
+    _ar_nar("tiny", "tiny_long", use_cache=True)
+    z = load_golden("full_b1_long")
+    phns, proms, langs = golden_inputs(z)
+    o = make_oracle("full", weight_seed=int(z["weight_seed"]))
+    codes, last = o.ar(phns, proms, langs, max_duration=40, temperature=0.0, use_cache=True, return_logits=True)
+    np.testing.assert_array_equal(codes[0].numpy(), z["ar_codes_0"][:40])
+    assert_close(torch.stack(last), z["ar_last_logits"][:40], 5e-4, 5e-4)
