@@ -43,7 +43,8 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "oracle"))
 
 import ref_harness as rh  # noqa: E402
-from vall_e_amd import config as vcfg  # noqa: E402
+sys.path.insert(0, str(ROOT / "tests"))
+import model_configs as vcfg  # noqa: E402  (tests/model_configs.py: the reduced-size configurations)
 from vall_e_amd.synth import synth_batch, synth_utterance, QNT_ENC_PHONEME_IDS  # noqa: E402
 from vall_e_amd.weights import synth_state_dict  # noqa: E402
 

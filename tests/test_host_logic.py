@@ -167,7 +167,7 @@ def test_weights_file_roundtrip_in_reference_format(tmp_path):
     """A file written the way Engines.export does (state dict + JSON `config`/`stats` metadata,
     vall_e/engines/base.py:356-401, utils/io.py:92-104) loads back into the same config and tensors."""
     import torch
-    from vall_e_amd.config import tiny_model
+    from model_configs import tiny_model
     from vall_e_amd.models import get_model
     from vall_e_amd.utils.io import load_model_file, torch_load, torch_save
     from vall_e_amd.weights import synth_state_dict
@@ -193,7 +193,7 @@ def test_inputs_structure_matches_reference_layout():
     plan_from_inputs turns them into the same plan as the keyword form."""
     import numpy as np
     import torch
-    from vall_e_amd.config import tiny_model
+    from model_configs import tiny_model
     from vall_e_amd.models import get_model
     from vall_e_amd.synth import synth_batch
     m = get_model(tiny_model())
@@ -296,7 +296,7 @@ def test_sequences_beyond_the_rope_table_are_refused():
     """Positions index a RoPE table of max_position_embeddings rows: longer sequences raise instead of reading past it."""
     import numpy as np
     from vall_e_amd.models import get_model
-    from vall_e_amd import config as vcfg
+    import model_configs as vcfg
     cfg = vcfg.tiny_model()
     cfg.experimental.max_position_embeddings = 64
     m = get_model(cfg, training=False)

@@ -6,7 +6,9 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from vall_e_amd import config as vcfg
 from vall_e_amd.models import get_model
 from vall_e_amd.weights import synth_state_dict
-cfg = vcfg.tiny_model()
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tests"))
+import model_configs as _mc
+cfg = _mc.tiny_model()
 m = get_model(cfg).load_state_dict(synth_state_dict(cfg, 1)).to("cuda:0", torch.float32)
 B, V, NP = 32, 1025, 2000
 g = torch.Generator().manual_seed(0)

@@ -144,73 +144,6 @@ def repo_default_model() -> Model:
     )
 
 
-def tiny_model(dim=256, heads=4, layers=2) -> Model:
-    """Reduced-size sibling of the repo default (same switches) for fast parity cases."""
-    m = repo_default_model()
-    m.size = {"dim": dim, "heads": heads, "layers": layers}
-    return m
-
-
-def tiny_len_model(**kw) -> Model:
-    """``tiny_model`` with the ``len`` capability: adds the 11-token duration head (base.py:404-406)."""
-    m = tiny_model(**kw)
-    m.capabilities = ["ar", "nar", "len"]
-    return m
-
-
-def tiny_tone_model(**kw) -> Model:
-    """``tiny_len_model`` with the ``tone`` capability: a tone token between prompt and response (base.py:623-624)."""
-    m = tiny_len_model(**kw)
-    m.capabilities = ["ar", "nar", "len", "tone"]
-    return m
-
-
-def tiny_upi_model(**kw) -> Model:
-    """``tiny_model`` with ``unified_position_ids`` (the reference's dataclass default, config.py:292): one arange over
-    the whole sequence instead of per-segment position ids."""
-    m = tiny_model(**kw)
-    m.experimental.unified_position_ids = True
-    return m
-
-
-def tiny_nobias_model(**kw) -> Model:
-    """``tiny_model`` with ``classifiers_bias=False``: heads without a bias vector (base.py:179-199)."""
-    m = tiny_model(**kw)
-    m.experimental.classifiers_bias = False
-    return m
-
-
-def tiny_nosum_model(**kw) -> Model:
-    """``tiny_model`` with the reference's dataclass default ``audio_embedding_sums=False`` (config.py:291; data/config.yaml
-    switches it on): a code frame is embedded by its last known level alone (base.py:169-173)."""
-    m = tiny_model(**kw)
-    m.experimental.audio_embedding_sums = False
-    return m
-
-
-def tiny_sumprom_model(**kw) -> Model:
-    """``audio_embedding_sums="prom"``: prompt frames summed over their levels, response frames not (base.py:434, :438)."""
-    m = tiny_model(**kw)
-    m.experimental.audio_embedding_sums = "prom"
-    return m
-
-
-def tiny_nc_model(**kw) -> Model:
-    """Tiny sibling of the published ``ar+nar-len-llama-8`` switches: ``len`` head and ``noncausal_masks``
-    (NAR levels attend in both directions, base.py:1230-1233)."""
-    m = tiny_len_model(**kw)
-    m.experimental.noncausal_masks = True
-    return m
-
-
-def tiny_nc_upi_model(**kw) -> Model:
-    """``tiny_nc_model`` with the reference's dataclass default ``unified_position_ids=True``: every switch of a
-    checkpoint whose config names only ``noncausal_masks`` and the ``len`` capability."""
-    m = tiny_nc_model(**kw)
-    m.experimental.unified_position_ids = True
-    return m
-
-
 @dataclass
 class Inference:
     # vall_e/config.py:849-862
