@@ -232,6 +232,12 @@ typedef struct {
     int32_t  resp_emb_row0;     /* row of resps_emb[0][0] in the concatenated table           */
     int      head;              /* classifier index (AR:0:0 = 0)                              */
     int      vocab;             /* columns of that head                                       */
+    int      early_exit;        /* 1: an utterance whose stop token was sampled leaves the step -- no KV append, no KV
+                                 * read (its attention workgroups return), nothing appended to seq, seq_len frozen and
+                                 * ctx_len[b] stored as ~ctx_len (negative: the mark the decode kernels test).  The reference keeps stepping finished utterances until all have stopped
+                                 * (models/ar_nar.py:837-848; its own to-do, docs/README.md:85); what it appends behind a
+                                 * stop token is cut off again (:870-872), so results are identical -- except for
+                                 * refine_on_stop (:874-883), which re-reads those rows: leave 0 there                  */
     int      max_ctx;           /* HOST-side upper bound on ctx_len[b] over the batch at the time of the call
                                  * (required, > 0): valle_ar_decode refuses n_steps that would write past
                                  * cache_T or read past the RoPE table -- the kernels do not check        */

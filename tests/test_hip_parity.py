@@ -359,6 +359,31 @@ def test_bench_shape_b16_bf16_vs_oracle(gpu_device, ragged):
         assert worst < 8e-2, (step, worst)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_early_exit_of_finished_utterances(gpu_device, dtype):
+    """valle_ar_state.early_exit (the reference's own to-do, docs/README.md:85; loop at ar_nar.py:837-848): utterances that
+    sampled their stop token leave the decode step -- no KV append, no KV read, nothing appended -- and the codes are the
+    ones the loop produces when it keeps stepping them.  Inputs of golden tiny_refine (two utterances that stop at
+    different steps), without the refine option.  fp32: equal to the oracle, which steps finished utterances on as the
+    reference does; bf16 (the fused kernels, where the attention workgroups actually return): equal to the same run with
+    early_exit off.  One decode step per chunk, so chunks start with one utterance already finished."""
+    z = load_golden("tiny_refine")
+    phns, proms, langs = golden_inputs(z)
+    m = hip_model("tiny", dtype, stop_bias=0.6)
+    kw = dict(task_list=["tts"] * 2, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=int(z["steps"]),
+              temperature=0.0, length_penalty=float(z["kw_length_penalty"]), step_chunk=1)
+    on = m(**kw)
+    off = m(**kw, early_exit=False)
+    for b in range(2):
+        assert torch.equal(on[b], off[b])
+    if dtype == torch.float32:
+        assert len({int(c.shape[0]) for c in on}) == 2, "the utterances must stop at different steps for this test to mean anything"
+        want = oracle("tiny", stop_bias=0.6).ar(phns, proms, langs, max_duration=int(z["steps"]), temperature=0.0,
+                                                length_penalty=float(z["kw_length_penalty"]))
+        for b in range(2):
+            np.testing.assert_array_equal(on[b].cpu().numpy(), want[b].numpy())
+
+
 def test_full_b3_ragged_codes_identical(gpu_device):
     _ar_nar("full", "full_b3")
 

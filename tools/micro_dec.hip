@@ -73,6 +73,9 @@ int main(int argc, char** argv) {
     FILL(x, 32 * d * 2, 1); FILL(att, 32 * d * 2, 2); FILL(ff, 32 * f * 2, 3); FILL(nw, d * 2, 4);
     FILL(qkv, B * 3 * d * 2, 5); CK(hipDeviceSynchronize()); CK(hipMemset(rope, 0, 1024 * 64 * 4)); CK(hipMemset(pos, 0, B * 4));
     { std::vector<int32_t> hc(B, ctx); CK(hipMemcpy(ctxl, hc.data(), B * 4, hipMemcpyHostToDevice)); }
+    // MICRO_STOPPED=n: the first n utterances count as finished (early exit): their attention workgroups leave at once
+    if (getenv("MICRO_STOPPED")) { std::vector<int32_t> hc(B, ctx); for (int i = 0; i < atoi(getenv("MICRO_STOPPED")) && i < B; ++i) hc[i] = ~ctx;
+        CK(hipMemcpy(ctxl, hc.data(), B * 4, hipMemcpyHostToDevice)); }
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int reps = force_eager ? 2 : 20;

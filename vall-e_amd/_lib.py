@@ -47,7 +47,7 @@ class ARState(C.Structure):
         ("seq", C.c_void_p), ("seq_len", C.c_void_p), ("ctx_len", C.c_void_p), ("resp_pos0", C.c_void_p),
         ("cache_slot", C.c_void_p), ("stopped", C.c_void_p), ("scores", C.c_void_p),
         ("kcache", C.c_void_p), ("vcache", C.c_void_p), ("cache_T", C.c_int), ("cache_layer_stride", C.c_size_t),
-        ("resp_emb_row0", C.c_int32), ("head", C.c_int), ("vocab", C.c_int), ("max_ctx", C.c_int),
+        ("resp_emb_row0", C.c_int32), ("head", C.c_int), ("vocab", C.c_int), ("early_exit", C.c_int), ("max_ctx", C.c_int),
     ]
 
 

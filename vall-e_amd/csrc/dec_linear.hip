@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64 * NWK) void dec_wave_kernel(const bf16* __restri
             }
             if (which == 0) {
                 *reinterpret_cast<bf16x4*>((bf16*)pOut + (size_t)m * a.ldo + n) = o;
-            } else {
+            } else if (cpos >= 0) {                    // a negative ctx_len marks a finished utterance (early exit): no append
                 bf16* cp = (which == 1 ? a.kc : a.vc) + (((size_t)csl * a.H + h) * a.cache_T + cpos) * 64 + e;
                 *reinterpret_cast<bf16x4*>(cp) = o;
             }

@@ -236,6 +236,8 @@ static int ar_decode_impl(valle_model* m, const valle_ar_state* st, const valle_
     hipStream_t s = (hipStream_t)stream;
     const bool wavepath = (dt == VALLE_BF16) && B <= 32 && (d == 256 || d == 512 || d == 768 || d == 1024) && f == 4 * d &&
                           m->layers[0].pn_qkv && m->layers[0].p_o && m->layers[0].pn_gu && m->layers[0].p_down && m->head_pn[st->head];
+    // early exit of finished utterances: only with the fused sampler (it freezes their seq_len / ctx_len) on the fused path
+    const bool early = st->early_exit != 0 && sp != nullptr && wavepath;
     int rc;
     for (int step = 0; step < n_steps; ++step) {
         float* lg = logits_out ? logits_out + (size_t)step * B * ld_logits : lg_ws;
@@ -301,7 +303,7 @@ static int ar_decode_impl(valle_model* m, const valle_ar_state* st, const valle_
         }
         sa.scores = st->scores;
         sa.seq = st->seq; sa.seq_cap = st->max_steps; sa.seq_len = st->seq_len; sa.ctx_len = st->ctx_len; sa.stopped = st->stopped;
-        sa.prev_is_seq = 1; sa.step = (uint64_t)step;
+        sa.prev_is_seq = 1; sa.step = (uint64_t)step; sa.early_exit = early ? 1 : 0;
         RUN(valle_sample_launch(sa, B, s));
     }
     return VALLE_OK;

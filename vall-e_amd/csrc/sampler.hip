@@ -366,11 +366,14 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
         a.ids[row] = tok;
         const float sc = expf(vals[tok] - mx) / se;
         if (a.scores) a.scores[row] = sc;
-        if (a.seq != nullptr) {  // fused AR append (models/ar_nar.py:837-842)
+        if (a.seq != nullptr && !(a.early_exit && a.stopped[item])) {  // fused AR append (models/ar_nar.py:837-842)
             const int n = a.seq_len[item];
             if (n < a.seq_cap) a.seq[(size_t)item * a.seq_cap + n] = tok;
             a.seq_len[item] = n + 1;
-            a.ctx_len[item] = a.ctx_len[item] + 1;
+            const int ctx1 = a.ctx_len[item] + 1;
+            // early exit: a finished utterance's context is stored as ~ctx_len (negative) -- the decode kernels read ctx_len
+            // anyway and leave on a negative value, with no further flag to fetch
+            a.ctx_len[item] = (a.early_exit && tok == a.p.stop_token) ? ~ctx1 : ctx1;
             if (tok == a.p.stop_token) a.stopped[item] = 1;
         }
     }
@@ -444,11 +447,14 @@ __global__ __launch_bounds__(64) void sample_greedy_wave_kernel(SampleArgs a) {
     if (lane == 0) {
         a.ids[row] = tok;
         if (a.scores) a.scores[row] = 1.0f / se;               // exp(x[tok] - mx) = 1; nan when the row is all -inf / nan
-        if (a.seq != nullptr) {                                 // fused AR append (models/ar_nar.py:837-842)
+        if (a.seq != nullptr && !(a.early_exit && a.stopped[item])) {   // fused AR append (models/ar_nar.py:837-842)
             const int n = a.seq_len[item];
             if (n < a.seq_cap) a.seq[(size_t)item * a.seq_cap + n] = tok;
             a.seq_len[item] = n + 1;
-            a.ctx_len[item] = a.ctx_len[item] + 1;
+            const int ctx1 = a.ctx_len[item] + 1;
+            // early exit: a finished utterance's context is stored as ~ctx_len (negative) -- the decode kernels read ctx_len
+            // anyway and leave on a negative value, with no further flag to fetch
+            a.ctx_len[item] = (a.early_exit && tok == a.p.stop_token) ? ~ctx1 : ctx1;
             if (tok == a.p.stop_token) a.stopped[item] = 1;
         }
     }

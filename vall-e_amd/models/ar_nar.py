@@ -146,6 +146,9 @@ class AR_NAR(Base):
         max_duration = kw.get("max_duration", 500)
         step_chunk = int(kw.pop("step_chunk", 32))
         return_logits = kw.pop("return_logits", False)
+        # finished utterances leave the decode step (valle_ar_state.early_exit) unless the caller wants what the reference
+        # computes behind a stop token: refine_on_stop re-reads those rows, return_logits returns them
+        early_exit = bool(kw.pop("early_exit", True))
         noalloc = kw.pop("noalloc", False)  # decode chunks through valle_ar_decode_noalloc (the library's static scratch array)
         prof = kw.pop("profile", None)      # list: receives (start_event, end_event, n_steps, ctx_len_host) per decode chunk
         prefix_context = kw.get("prefix_context", None)
@@ -222,7 +225,8 @@ class AR_NAR(Base):
             resp_pos0 = self._i32([plan.lens[i] - len(prefix[i]) if self.unified_position_ids else 0 for i in range(B)])
             st = L.ARState(B, cap, seq.data_ptr(), seq_len.data_ptr(), ctx_len.data_ptr(), resp_pos0.data_ptr(),
                            slot.data_ptr(), stopped.data_ptr(), scores.data_ptr(), kc.data_ptr(), vc.data_ptr(),
-                           cache_T, stride, self._off["resp0"], 0, V, int(plan.max_T))
+                           cache_T, stride, self._off["resp0"], 0, V,
+                           1 if early_exit and not refine_on_stop and not return_logits else 0, int(plan.max_T))
             states.append((st, (kc, vc, ctx_len, resp_pos0), int(plan.max_T)))
             first_logits.append(lg)
         ws_bytes = lib.valle_decode_workspace_bytes(self._handle, B)
