@@ -103,6 +103,18 @@ int valle_rope_kv(void* qkv, const int32_t* pos, const float* rope, const int32_
 int valle_attn_prefill(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int M, int max_T,
                        int H, int Dh, int causal, int dtype, void* stream);
 
+/* The same attention on separate q, k, v tensors of shape (B, H, T, Dh) with arbitrary batch / head / row strides
+ * (elements; the last dimension contiguous) -- the form the reference's attention plug-in point passes
+ * (arch/llama.py:396-403 `fused_attn_func(q, k, v, causal=, softmax_scale=, dropout_p=)`, backend registry
+ * arch/attention/__init__.py:11-198; (B, T, H, Dh) tensors of the flash_attn branch, llama.py:328-339, are the same call with
+ * the head and row strides swapped).  *_strides = {batch, head, row}.  seqlens (device int32 [B], optional): utterance b
+ * attends over its first seqlens[b] rows only and rows at or beyond seqlens[b] of `out` are not written -- the padding the
+ * reference's own fused kernel leaves unmasked (arch/attention/fused.py has no mask argument).  bf16, Dh == 64. */
+int valle_attn_prefill_hnd(const void* q, const void* k, const void* v, void* out, int B, int H, int T, int Dh,
+                           const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                           const int64_t* out_strides, int causal, float softmax_scale, const int32_t* seqlens,
+                           int dtype, void* stream);
+
 /* One-query-per-utterance attention against the KV cache (the KV-cache restatement of the
  * reference's full recompute, models/base.py:521 use_cache=False).  q rows come from qkv [B][3d];
  * utterance b reads ctx_len[b] cached positions of slot cache_slot[b]. */

@@ -62,6 +62,9 @@ SIGNATURES = {
     "valle_rope_kv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                               c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "valle_attn_prefill": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "valle_attn_prefill_hnd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                       c_int, c_float, c_void_p, c_int, c_void_p]),
     "valle_attn_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int, c_void_p]),
     "valle_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
@@ -120,6 +123,11 @@ def ptr(t):
     if t is None:
         return None
     assert t.is_contiguous(), "C-ABI calls take contiguous buffers"
+    return C.c_void_p(t.data_ptr())
+
+
+def ptr_any(t):
+    """Device pointer of a tensor that may be a strided view."""
     return C.c_void_p(t.data_ptr())
 
 

@@ -21,15 +21,32 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 // feeds QB MFMAs.  K/V tiles are double-buffered in LDS: one barrier per tile.  Four waves per SIMD (128 VGPRs; two
 // values spill outside the loop): the softmax is a long dependent chain per tile, and residency is what hides it
 // (2 / 3 / 4 waves per SIMD: 68 / 57 / 54 us at 16 x 761 tokens).
+// Where the rows live.  Token-packed qkv (the model's own layout): q / k / v = qkv + {0, d, 2d}, row stride 3d, head
+// stride 64, utterance b starts at row cu[b].  Strided (B, H, T, 64) tensors (the reference's attention plug-in point,
+// arch/llama.py:396-403): one batch / head / row stride per tensor, T keys per utterance or seqlens[b] of them.
+struct FlashAddr {
+    const bf16 *q, *k, *v; bf16* out;
+    long q_bs, q_hs, q_rs, k_bs, k_hs, k_rs, v_bs, v_hs, v_rs, o_bs, o_hs, o_rs;   // elements
+    const int32_t* cu;          // packed: row offsets [B + 1]; NULL: strided
+    const int32_t* seqlens;     // strided: valid rows per utterance (NULL: T_fixed)
+    int T_fixed;
+    float scale_log2;           // softmax scale x log2(e)
+};
+
 template <int QB>
-__global__ __launch_bounds__(256, 4) void attn_flash_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                              const int32_t* __restrict__ cu, int H, int causal) {
+__global__ __launch_bounds__(256, 4) void attn_flash_bf16_kernel(FlashAddr A, int causal) {
     constexpr int QT = 64 * QB;                               // queries per workgroup
     // causal: the last query tiles have the most key tiles -- dispatch them first so the grid's tail is made of short ones
     const int qt = causal ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int start = cu[b], T = cu[b + 1] - start;
+    int start = 0, T;
+    if (A.cu) { start = A.cu[b]; T = A.cu[b + 1] - start; }
+    else T = A.seqlens ? min(A.seqlens[b], A.T_fixed) : A.T_fixed;
     if (qt * QT >= T) return;
-    const int d = H * 64, ld = 3 * d;
+    const long brow = A.cu ? (long)start : 0, bidx = A.cu ? 0 : (long)b;     // packed: row offset; strided: batch index
+    const bf16* qbase = A.q + bidx * A.q_bs + brow * A.q_rs + (long)h * A.q_hs;
+    const bf16* kbase = A.k + bidx * A.k_bs + brow * A.k_rs + (long)h * A.k_hs;
+    const bf16* vbase = A.v + bidx * A.v_bs + brow * A.v_rs + (long)h * A.v_hs;
+    bf16* obase = A.out + bidx * A.o_bs + brow * A.o_rs + (long)h * A.o_hs;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     __shared__ __attribute__((aligned(16))) bf16 Ks[2][64 * FA_ROW];
@@ -41,7 +58,7 @@ __global__ __launch_bounds__(256, 4) void attn_flash_bf16_kernel(const bf16* __r
     for (int j = 0; j < QB; ++j) {
         q[j] = qt * QT + (wave * QB + j) * 16 + fr;
         const int qc = q[j] < T ? q[j] : T - 1;
-        const bf16* qp = qkv + (size_t)(start + qc) * ld + h * 64 + fq * 8;
+        const bf16* qp = qbase + (long)qc * A.q_rs + fq * 8;
         qf[j][0] = *reinterpret_cast<const bf16x8*>(qp);
         qf[j][1] = *reinterpret_cast<const bf16x8*>(qp + 32);
     }
@@ -57,19 +74,19 @@ __global__ __launch_bounds__(256, 4) void attn_flash_bf16_kernel(const bf16* __r
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[j][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    const float sc = 0.125f * 1.4426950408889634f;            // 1/sqrt(64) * log2(e)
+    const float sc = A.scale_log2;                            // softmax scale (1/sqrt(64) in the model) x log2(e); > 0
 
     // the next tile's K/V rows wait in four named registers (as arrays behind a lambda the compiler kept them in
     // scratch memory, which put the global-load latency back on the critical path of every tile)
     uint4 kr0, kr1, vr0, vr1;
     const int lrow = tid >> 3, lch = tid & 7;                 // this thread stages rows lrow and lrow + 32, 16-byte piece lch
-    const bf16* kvbase = qkv + (size_t)start * ld + d + h * 64 + lch * 8;
+    const bf16* kl = kbase + lch * 8;
+    const bf16* vl = vbase + lch * 8;
 #define FA_GLOAD(KT) do { \
         int key0 = (KT) * 64 + lrow, key1 = key0 + 32; \
         key0 = key0 < T ? key0 : T - 1; key1 = key1 < T ? key1 : T - 1; \
-        const bf16* p0 = kvbase + (size_t)key0 * ld; const bf16* p1 = kvbase + (size_t)key1 * ld; \
-        kr0 = *reinterpret_cast<const uint4*>(p0); vr0 = *reinterpret_cast<const uint4*>(p0 + d); \
-        kr1 = *reinterpret_cast<const uint4*>(p1); vr1 = *reinterpret_cast<const uint4*>(p1 + d); \
+        kr0 = *reinterpret_cast<const uint4*>(kl + (long)key0 * A.k_rs); vr0 = *reinterpret_cast<const uint4*>(vl + (long)key0 * A.v_rs); \
+        kr1 = *reinterpret_cast<const uint4*>(kl + (long)key1 * A.k_rs); vr1 = *reinterpret_cast<const uint4*>(vl + (long)key1 * A.v_rs); \
     } while (0)
     FA_GLOAD(0);
     // per-lane LDS offsets (elements) inside a tile, fixed for the whole loop: every access below is base + constant
@@ -175,7 +192,7 @@ __global__ __launch_bounds__(256, 4) void attn_flash_bf16_kernel(const bf16* __r
         lt += __shfl_xor(lt, 32, 64);
         if (q[j] < T) {
             const float inv = 1.0f / lt;
-            bf16* op = out + (size_t)(start + q[j]) * d + h * 64 + fq * 4;
+            bf16* op = obase + (long)q[j] * A.o_rs + fq * 4;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 bf16x4 ov;
@@ -189,15 +206,53 @@ __global__ __launch_bounds__(256, 4) void attn_flash_bf16_kernel(const bf16* __r
 
 #undef FA_GLOAD
 
-int valle_attn_flash_bf16(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int max_T, int H, int causal,
-                          hipStream_t s) {
+static int flash_launch(const FlashAddr& A, int B, int max_T, int H, int causal, hipStream_t s) {
     if (max_T > 256) {
         dim3 grid(ceil_div(max_T, 128), H, B);
-        attn_flash_bf16_kernel<2><<<grid, 256, 0, s>>>((const bf16*)qkv, (bf16*)out, cu_seqlens, H, causal);
+        attn_flash_bf16_kernel<2><<<grid, 256, 0, s>>>(A, causal);
     } else {
         dim3 grid(ceil_div(max_T, 64), H, B);
-        attn_flash_bf16_kernel<1><<<grid, 256, 0, s>>>((const bf16*)qkv, (bf16*)out, cu_seqlens, H, causal);
+        attn_flash_bf16_kernel<1><<<grid, 256, 0, s>>>(A, causal);
     }
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
+}
+
+int valle_attn_flash_bf16(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int max_T, int H, int causal,
+                          hipStream_t s) {
+    const long d = (long)H * 64;
+    FlashAddr A{};
+    A.q = (const bf16*)qkv; A.k = A.q + d; A.v = A.q + 2 * d; A.out = (bf16*)out;
+    A.q_rs = A.k_rs = A.v_rs = 3 * d; A.o_rs = d;
+    A.q_hs = A.k_hs = A.v_hs = A.o_hs = 64;
+    A.cu = cu_seqlens; A.scale_log2 = 0.125f * 1.4426950408889634f;
+    return flash_launch(A, B, max_T, H, causal, s);
+}
+
+extern "C" int valle_attn_prefill_hnd(const void* q, const void* k, const void* v, void* out, int B, int H, int T, int Dh,
+                                      const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                      const int64_t* out_strides, int causal, float softmax_scale, const int32_t* seqlens,
+                                      int dtype, void* stream) {
+    VALLE_REQUIRE(q && k && v && out && q_strides && k_strides && v_strides && out_strides, VALLE_E_ARG, "valle_attn_prefill_hnd: null pointer");
+    VALLE_REQUIRE(B > 0 && H > 0 && T > 0, VALLE_E_ARG, "valle_attn_prefill_hnd: empty shape (B=%d, H=%d, T=%d)", B, H, T);
+    VALLE_REQUIRE(softmax_scale > 0.f, VALLE_E_ARG, "valle_attn_prefill_hnd: softmax_scale must be positive");
+    if (dtype != VALLE_BF16 || Dh != 64) {
+        valle_set_error("valle_attn_prefill_hnd: built for bf16 and head_dim 64 (got dtype %d, head_dim %d)", dtype, Dh);
+        return VALLE_E_UNSUPPORTED;
+    }
+    const int64_t* st[4] = {q_strides, k_strides, v_strides, out_strides};
+    const void* ptrs[4] = {q, k, v, out};
+    for (int i = 0; i < 4; ++i) {
+        VALLE_REQUIRE(st[i][0] % 4 == 0 && st[i][1] % 4 == 0 && st[i][2] % 4 == 0 && (i == 3 || (st[i][0] % 8 == 0 && st[i][1] % 8 == 0 && st[i][2] % 8 == 0)),
+                      VALLE_E_ARG, "valle_attn_prefill_hnd: strides must keep rows 16-byte aligned (8 bytes for out)");
+        VALLE_REQUIRE(((uintptr_t)ptrs[i] & (i == 3 ? 7 : 15)) == 0, VALLE_E_ARG, "valle_attn_prefill_hnd: misaligned tensor");
+    }
+    FlashAddr A{};
+    A.q = (const bf16*)q; A.k = (const bf16*)k; A.v = (const bf16*)v; A.out = (bf16*)out;
+    A.q_bs = q_strides[0]; A.q_hs = q_strides[1]; A.q_rs = q_strides[2];
+    A.k_bs = k_strides[0]; A.k_hs = k_strides[1]; A.k_rs = k_strides[2];
+    A.v_bs = v_strides[0]; A.v_hs = v_strides[1]; A.v_rs = v_strides[2];
+    A.o_bs = out_strides[0]; A.o_hs = out_strides[1]; A.o_rs = out_strides[2];
+    A.seqlens = seqlens; A.T_fixed = T; A.scale_log2 = softmax_scale * 1.4426950408889634f;
+    return flash_launch(A, B, T, H, causal, (hipStream_t)stream);
 }
