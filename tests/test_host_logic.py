@@ -328,3 +328,34 @@ def test_from_dict_refuses_unbuilt_experimental_switches():
     with pytest.raises(NotImplementedError):
         Model.from_dict({"size": {"dim": 1024, "heads": 16, "layers": 12, "embed_dim": 512}})
     Model.from_dict({"size": {"dim": 1024, "heads": 16, "layers": 12, "embed_dim": 1024}, "experimental": {"kv_heads": 16}})
+
+
+def test_hf_token_ranges_and_round_trip():
+    """The HF / gguf layout (export.py:81-108): the ranges for the published ar+nar-len-llama-8 shape are the ones
+    vall_e.cpp:14-41 and base.py:64-90 hard-code, and to_hf_llama -> from_hf_llama returns every tensor the layout carries."""
+    from vall_e_amd.config import Model, ModelExperimentalSettings
+    from vall_e_amd.utils.hf_layout import from_hf_llama, io_ranges, to_hf_llama
+    from vall_e_amd.weights import synth_state_dict
+    pub = Model(name="ar+nar-len", size="full", tasks=9, langs=6, tones=1, capabilities=["ar", "nar", "len"],
+                experimental=ModelExperimentalSettings(audio_embedding_sums=True, split_classifiers=True, noncausal_masks=True))
+    r = io_ranges(pub)
+    want = {"text": (0, 256, 9), "rvq_l": (256, 264, -1), "lang": (264, 270, -1), "task": (270, 279, -1), "len": (279, 290, 10),
+            "tone": (290, 291, -1), "sep": (291, 292, -1), "prom|0": (292, 1316, -1), "prom|7": (7460, 8484, -1),
+            "resps|AR:0:0": (8484, 9509, 0), "resps|NAR:0:1": (9509, 10533, 1), "resps|NAR:6:7": (15653, 16677, 7),
+            "resps|NAR:0:0": (16677, 17702, 8)}
+    for k, (s, e, h) in want.items():
+        assert (r[k][0], r[k][1], r[k][3]) == (s, e, h), k
+    import model_configs as mc
+    cfg = mc.tiny_nc_model()
+    cfg.langs = 6
+    sd = synth_state_dict(cfg, 5)
+    hf = to_hf_llama(sd, cfg)
+    assert hf["model.embed_tokens.weight"].shape == hf["lm_head.weight"].shape == (17702, cfg.dim)
+    back = from_hf_llama(hf, cfg)
+    for k, v in sd.items():
+        if k in ("raw_text_emb.weight", "dropout_token"):
+            assert not back[k].any()
+        else:
+            assert torch.equal(back[k], v), k
+    from vall_e_amd.models import get_model
+    get_model(cfg).load_state_dict(back, strict=True)
