@@ -170,6 +170,34 @@ int valle_sample(const float* logits, int ld, int vocab, int rows, const int32_t
 int valle_cfg_combine(float* pos, const float* neg, int ld, int vocab, const int32_t* row_off, int B,
                       float strength, float rescale, void* stream);
 
+/* The guidance of the AR loop (models/ar_nar.py:785-800 -> samplers.py:177-191): utterance i's rows are
+ * [row_start[i], row_start[i] + row_count[i]) of two READ-ONLY row matrices (the per-step logit histories of the
+ * conditional and the null pass; the statistics run over all of them) and only the combination of its LAST row is written,
+ * to out[i][0..vocab) (ld_out floats per row). */
+int valle_cfg_combine_last(const float* pos, const float* neg, int ld, int vocab, const int32_t* row_start,
+                           const int32_t* row_count, int B, float strength, float rescale, float* out, int ld_out,
+                           void* stream);
+
+/* One host-driven AR step (the prefill's row, every step of the guidance loop): valle_sample in AR mode on logits [B][ld]
+ * with prev = seq[b][:seq_len[b]], then the append of models/ar_nar.py:837-848 on the device: seq[b][seq_len[b]] = token,
+ * seq_len[b] += 1, stopped[b] |= (token == stop_token), and ctx_len[b] += 1 / ctx_len2[b] += 1 for the caches that ran
+ * the token through the stack (either may be NULL).  ids [B] and scores [B] (may be NULL) as valle_sample. */
+int valle_sample_append(const float* logits, int ld, int vocab, int B, const valle_sample_params* params,
+                        int32_t* seq, int seq_cap, int32_t* seq_len, int32_t* ctx_len, int32_t* ctx_len2,
+                        int32_t* stopped, int32_t* ids, float* scores, void* stream);
+
+/* Integer table patch: dst[rows[i]][c0 + c] = src[i][s0 + c] + add for i < n, c < ncols (rows == NULL: row i; dst int32 or,
+ * dst_is_i64 != 0, int64).  The host plans the gather tables of a dense pass before the codes exist (Base.inputs,
+ * models/base.py:560-735); the device fills in the codes as they are sampled (the torch.cat / tensor rebuilds of
+ * models/ar_nar.py:523-525, :575-584, :363). */
+int valle_scatter_cols(void* dst, int dst_is_i64, int ld_dst, const int32_t* rows, const int32_t* src, int ld_src,
+                       int n, int c0, int s0, int ncols, int add, void* stream);
+
+/* End of a NAR-len demasking step (models/ar_nar.py:457-462): codes[j] = ids[j] where is_masked[j]; scores[j] = sc[j], or
+ * with masked_only (sampling_scores_masked_only) sc[j] where is_masked[j] and 1.0 elsewhere. */
+int valle_narlen_commit(int32_t* codes, float* scores, const uint8_t* is_masked, const int32_t* ids, const float* sc,
+                        int n, int masked_only, void* stream);
+
 /* NAR-len masking step (models/ar_nar.py:358-365): for utterance i with scores
  * s[off[i] .. off[i+1]), sets codes[j] = mask_token at the k[i] lowest-score positions
  * (ties broken by lower index) and writes is_masked[j] = (codes[j] == mask_token).

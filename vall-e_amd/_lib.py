@@ -70,6 +70,11 @@ SIGNATURES = {
     "valle_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                              C.POINTER(SampleParams), c_void_p, c_void_p, c_void_p]),
     "valle_cfg_combine": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_float, c_float, c_void_p]),
+    "valle_cfg_combine_last": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_int, c_void_p]),
+    "valle_sample_append": (c_int, [c_void_p, c_int, c_int, c_int, C.POINTER(SampleParams), c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    "valle_scatter_cols": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "valle_narlen_commit": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "valle_mask_lowest": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "valle_model_create": (c_int, [C.POINTER(Config), c_void_p, c_void_p, C.POINTER(LayerWeights), c_void_p, c_int,
                                    C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(C.c_int32), C.POINTER(c_void_p), C.POINTER(c_void_p)]),

@@ -88,6 +88,7 @@ struct SampleArgs {
     int32_t* ids; float* scores;
     // optional fused AR bookkeeping (valle_ar_decode): row == utterance
     int32_t* seq; int seq_cap; int32_t* seq_len; int32_t* ctx_len; int32_t* stopped;
+    int32_t* ctx_len2;          // optional second context counter (the null-prompt cache of the guidance loop)
     int early_exit;             // rows whose utterance has stopped[] set append nothing and keep seq_len / ctx_len
     int prev_is_seq;            // prev tokens of row i = seq[i*seq_cap .. + seq_len[i])
     uint64_t step;              // added to the Philox offset

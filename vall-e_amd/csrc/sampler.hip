@@ -370,10 +370,13 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
             const int n = a.seq_len[item];
             if (n < a.seq_cap) a.seq[(size_t)item * a.seq_cap + n] = tok;
             a.seq_len[item] = n + 1;
-            const int ctx1 = a.ctx_len[item] + 1;
-            // early exit: a finished utterance's context is stored as ~ctx_len (negative) -- the decode kernels read ctx_len
-            // anyway and leave on a negative value, with no further flag to fetch
-            a.ctx_len[item] = (a.early_exit && tok == a.p.stop_token) ? ~ctx1 : ctx1;
+            if (a.ctx_len) {
+                const int ctx1 = a.ctx_len[item] + 1;
+                // early exit: a finished utterance's context is stored as ~ctx_len (negative) -- the decode kernels read
+                // ctx_len anyway and leave on a negative value, with no further flag to fetch
+                a.ctx_len[item] = (a.early_exit && tok == a.p.stop_token) ? ~ctx1 : ctx1;
+            }
+            if (a.ctx_len2) a.ctx_len2[item] = a.ctx_len2[item] + 1;     // second cache of the guidance loop
             if (tok == a.p.stop_token) a.stopped[item] = 1;
         }
     }
@@ -451,10 +454,13 @@ __global__ __launch_bounds__(64) void sample_greedy_wave_kernel(SampleArgs a) {
             const int n = a.seq_len[item];
             if (n < a.seq_cap) a.seq[(size_t)item * a.seq_cap + n] = tok;
             a.seq_len[item] = n + 1;
-            const int ctx1 = a.ctx_len[item] + 1;
-            // early exit: a finished utterance's context is stored as ~ctx_len (negative) -- the decode kernels read ctx_len
-            // anyway and leave on a negative value, with no further flag to fetch
-            a.ctx_len[item] = (a.early_exit && tok == a.p.stop_token) ? ~ctx1 : ctx1;
+            if (a.ctx_len) {
+                const int ctx1 = a.ctx_len[item] + 1;
+                // early exit: a finished utterance's context is stored as ~ctx_len (negative) -- the decode kernels read
+                // ctx_len anyway and leave on a negative value, with no further flag to fetch
+                a.ctx_len[item] = (a.early_exit && tok == a.p.stop_token) ? ~ctx1 : ctx1;
+            }
+            if (a.ctx_len2) a.ctx_len2[item] = a.ctx_len2[item] + 1;     // second cache of the guidance loop
             if (tok == a.p.stop_token) a.stopped[item] = 1;
         }
     }
@@ -507,11 +513,16 @@ extern "C" int valle_sample(const float* logits, int ld, int vocab, int rows, co
 }
 
 // ---------------------------------------------------------------------- cfg_combine
+// LAST = false: utterance i owns rows [row_a[i], row_a[i + 1]), every row is rewritten in place.
+// LAST = true: utterance i owns rows [row_a[i], row_a[i] + row_n[i]) of two read-only row matrices (the logit histories of
+// the AR guidance loop) and only its last row's combination is written, to out_last[i].
+template <bool LAST>
 __global__ __launch_bounds__(1024) void cfg_combine_kernel(float* __restrict__ pos, const float* __restrict__ neg, int ld,
-                                                           int vocab, const int32_t* __restrict__ row_off,
-                                                           float strength, float rescale) {
+                                                           int vocab, const int32_t* __restrict__ row_a,
+                                                           const int32_t* __restrict__ row_n, float* __restrict__ out_last,
+                                                           int ld_out, float strength, float rescale) {
     const int i = blockIdx.x;
-    const int r0 = row_off[i], r1 = row_off[i + 1];
+    const int r0 = row_a[i], r1 = LAST ? r0 + row_n[i] : row_a[i + 1];
     const long n = (long)(r1 - r0) * vocab;
     if (n <= 0) return;
     __shared__ double red[2][16];
@@ -547,14 +558,15 @@ __global__ __launch_bounds__(1024) void cfg_combine_kernel(float* __restrict__ p
         factor = rescale * (sdp / sdm) + (1.0f - rescale);
     }
     __syncthreads();
-    for (int r = r0; r < r1; ++r) {
+    for (int r = LAST ? r1 - 1 : r0; r < r1; ++r) {
         float* pr = pos + (size_t)r * ld;
         const float* nr = neg + (size_t)r * ld;
+        float* dst = LAST ? out_last + (size_t)i * ld_out : pr;
         for (int v = threadIdx.x; v < vocab; v += 1024) {
             const float p = pr[v], q = nr[v];
             float s = q + (p - q) * strength;
             if (rescale > 0.f) s = s * factor;
-            pr[v] = s;
+            dst[v] = s;
         }
     }
     (void)stat;
@@ -565,7 +577,18 @@ extern "C" int valle_cfg_combine(float* pos, const float* neg, int ld, int vocab
     VALLE_REQUIRE(pos && neg && row_off, VALLE_E_ARG, "valle_cfg_combine: null pointer");
     VALLE_REQUIRE(vocab > 0 && ld >= vocab, VALLE_E_ARG, "valle_cfg_combine: bad vocab/ld");
     if (B == 0) return VALLE_OK;
-    cfg_combine_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(pos, neg, ld, vocab, row_off, strength, rescale);
+    cfg_combine_kernel<false><<<B, 1024, 0, (hipStream_t)stream>>>(pos, neg, ld, vocab, row_off, nullptr, nullptr, 0, strength, rescale);
+    VALLE_LAUNCH_CHECK();
+    return VALLE_OK;
+}
+
+extern "C" int valle_cfg_combine_last(const float* pos, const float* neg, int ld, int vocab, const int32_t* row_start,
+                                      const int32_t* row_count, int B, float strength, float rescale, float* out, int ld_out,
+                                      void* stream) {
+    VALLE_REQUIRE(pos && neg && row_start && row_count && out, VALLE_E_ARG, "valle_cfg_combine_last: null pointer");
+    VALLE_REQUIRE(vocab > 0 && ld >= vocab && ld_out >= vocab, VALLE_E_ARG, "valle_cfg_combine_last: bad vocab/ld");
+    if (B == 0) return VALLE_OK;
+    cfg_combine_kernel<true><<<B, 1024, 0, (hipStream_t)stream>>>((float*)pos, neg, ld, vocab, row_start, row_count, out, ld_out, strength, rescale);
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
 }
@@ -601,6 +624,67 @@ extern "C" int valle_mask_lowest(const float* scores, int32_t* codes, uint8_t* i
     VALLE_REQUIRE(max_len >= 0 && max_len <= MASK_MAXN, VALLE_E_UNSUPPORTED, "valle_mask_lowest: %d positions per utterance (max %d)", max_len, MASK_MAXN);
     if (B == 0) return VALLE_OK;
     mask_lowest_kernel<<<B, 256, 0, (hipStream_t)stream>>>(scores, codes, is_masked, off, k, mask_token);
+    VALLE_LAUNCH_CHECK();
+    return VALLE_OK;
+}
+
+// ---------------------------------------------------------------------- host-driven AR step: sample + append
+extern "C" int valle_sample_append(const float* logits, int ld, int vocab, int B, const valle_sample_params* params,
+                                   int32_t* seq, int seq_cap, int32_t* seq_len, int32_t* ctx_len, int32_t* ctx_len2,
+                                   int32_t* stopped, int32_t* ids, float* scores, void* stream) {
+    VALLE_REQUIRE(logits && params && seq && seq_len && stopped && ids, VALLE_E_ARG, "valle_sample_append: null pointer");
+    VALLE_REQUIRE(vocab > 1 && vocab <= SAMP_MAXV && ld >= vocab && seq_cap > 0, VALLE_E_ARG, "valle_sample_append: vocab %d, ld %d, seq_cap %d", vocab, ld, seq_cap);
+    VALLE_REQUIRE(params->rep_pen_passes >= 1 && params->rep_pen_passes <= 2 && params->filter_passes >= 0 && params->filter_passes <= 2,
+                  VALLE_E_ARG, "valle_sample_append: rep_pen_passes / filter_passes out of range");
+    if (B == 0) return VALLE_OK;
+    SampleArgs a{};
+    a.logits = logits; a.ld = ld; a.vocab = vocab; a.nar_mode = 0; a.p = *params;
+    a.ids = ids; a.scores = scores;
+    a.seq = seq; a.seq_cap = seq_cap; a.seq_len = seq_len; a.ctx_len = ctx_len; a.ctx_len2 = ctx_len2; a.stopped = stopped;
+    a.prev_is_seq = 1;
+    return valle_sample_launch(a, B, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------- integer bookkeeping of the NAR / NAR-len loops
+template <typename D>
+__global__ __launch_bounds__(256) void scatter_cols_kernel(D* __restrict__ dst, int ld_dst, const int32_t* __restrict__ rows,
+                                                           const int32_t* __restrict__ src, int ld_src, int n, int c0, int s0,
+                                                           int ncols, int add) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * ncols) return;
+    const int i = t / ncols, c = t - i * ncols;
+    const int r = rows ? rows[i] : i;
+    dst[(size_t)r * ld_dst + c0 + c] = (D)(src[(size_t)i * ld_src + s0 + c] + add);
+}
+
+extern "C" int valle_scatter_cols(void* dst, int dst_is_i64, int ld_dst, const int32_t* rows, const int32_t* src, int ld_src,
+                                  int n, int c0, int s0, int ncols, int add, void* stream) {
+    VALLE_REQUIRE(dst && src, VALLE_E_ARG, "valle_scatter_cols: null pointer");
+    VALLE_REQUIRE(n >= 0 && ncols >= 0 && c0 >= 0 && s0 >= 0 && c0 + ncols <= ld_dst && s0 + ncols <= ld_src, VALLE_E_ARG,
+                  "valle_scatter_cols: columns out of range (c0 %d + %d of %d, s0 %d + %d of %d)", c0, ncols, ld_dst, s0, ncols, ld_src);
+    if (n == 0 || ncols == 0) return VALLE_OK;
+    const int grid = ceil_div(n * ncols, 256);
+    if (dst_is_i64) scatter_cols_kernel<long long><<<grid, 256, 0, (hipStream_t)stream>>>((long long*)dst, ld_dst, rows, src, ld_src, n, c0, s0, ncols, add);
+    else scatter_cols_kernel<int32_t><<<grid, 256, 0, (hipStream_t)stream>>>((int32_t*)dst, ld_dst, rows, src, ld_src, n, c0, s0, ncols, add);
+    VALLE_LAUNCH_CHECK();
+    return VALLE_OK;
+}
+
+__global__ __launch_bounds__(256) void narlen_commit_kernel(int32_t* __restrict__ codes, float* __restrict__ scores,
+                                                            const uint8_t* __restrict__ is_masked, const int32_t* __restrict__ ids,
+                                                            const float* __restrict__ sc, int n, int masked_only) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const bool m = is_masked[j] != 0;
+    if (m) codes[j] = ids[j];                                        // ar_nar.py:457: unmasked positions keep their token
+    scores[j] = masked_only ? (m ? sc[j] : 1.0f) : sc[j];            // ar_nar.py:459-462
+}
+
+extern "C" int valle_narlen_commit(int32_t* codes, float* scores, const uint8_t* is_masked, const int32_t* ids, const float* sc,
+                                   int n, int masked_only, void* stream) {
+    VALLE_REQUIRE(codes && scores && is_masked && ids && sc, VALLE_E_ARG, "valle_narlen_commit: null pointer");
+    if (n <= 0) return VALLE_OK;
+    narlen_commit_kernel<<<ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(codes, scores, is_masked, ids, sc, n, masked_only);
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
 }

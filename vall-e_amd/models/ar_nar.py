@@ -34,7 +34,8 @@ def _host_codes(tensors):
     """list of (R_i, L) integer tensors -> list of int64 numpy arrays, with ONE device->host copy when
     they live on a GPU (a .cpu() per utterance costs ~40 us of synchronisation each)."""
     if all(isinstance(t, torch.Tensor) and t.is_cuda for t in tensors) and len({t.shape[1:] for t in tensors}) == 1:
-        flat = torch.cat([t.long() for t in tensors]).cpu().numpy()
+        flat = torch.cat(list(tensors)).cpu().numpy().astype(np.int64) if len({t.dtype for t in tensors}) == 1 else \
+            torch.cat([t.long() for t in tensors]).cpu().numpy()
         cuts = np.cumsum([0] + [t.shape[0] for t in tensors])
         return [flat[cuts[i]:cuts[i + 1]] for i in range(len(tensors))]
     return [_np(t) for t in tensors]
@@ -272,24 +273,23 @@ class AR_NAR(Base):
             hcap = maxp + n_steps + 1
             hist = [torch.zeros((B, hcap, ld), dtype=torch.float32, device=dev) for _ in range(2)]
             foff = np.concatenate(([0], np.cumsum(n_prefix + 1)))
+            for k in range(2):                                                 # the prefill's rows open the histories
+                for b in range(B):
+                    hist[k][b, maxp - n_prefix[b]: maxp + 1] = first_logits[k][foff[b]:foff[b + 1]]
+            row_start = self._i32([b * hcap + maxp - int(n_prefix[b]) for b in range(B)])
+            last = torch.empty((B, ld), dtype=torch.float32, device=dev)
             for step in range(n_steps):
-                for k in range(2):
-                    if step == 0:
-                        for b in range(B):
-                            hist[k][b, maxp - n_prefix[b]: maxp + 1] = first_logits[k][foff[b]:foff[b + 1]]
-                    else:
-                        lg = torch.empty((B, ld), dtype=torch.float32, device=dev)
+                if step > 0:
+                    for k in range(2):
+                        # the step's logits land in their history row: logits_out = hist[k][:, maxp + step], row stride hcap * ld
                         states[k][0].max_ctx = states[k][2] + step - 1
-                        L.check(lib.valle_ar_decode(self._handle, C.byref(states[k][0]), None, 1, L.ptr(lg), ld,
+                        L.check(lib.valle_ar_decode(self._handle, C.byref(states[k][0]), None, 1,
+                                                    C.c_void_p(hist[k].data_ptr() + (maxp + step) * ld * 4), hcap * ld,
                                                     L.ptr(ws), ws.numel(), stream))
-                        hist[k][:, maxp + step] = lg
-                n_rows = n_prefix + step + 1
-                roff = np.concatenate(([0], np.cumsum(n_rows))).astype(np.int32)
-                sel = torch.from_numpy(np.concatenate([b * hcap + np.arange(maxp - n_prefix[b], maxp + step + 1) for b in range(B)])).to(dev)
-                posl = hist[0].view(B * hcap, ld).index_select(0, sel)
-                negl = hist[1].view(B * hcap, ld).index_select(0, sel)
-                self.cfg_combine(posl, negl, V, roff, cfg_strength, cfg_rescale)
-                last = posl.index_select(0, torch.from_numpy(roff[1:].astype(np.int64) - 1).to(dev)).contiguous()
+                # guidance over every response row so far (std over rows x vocab, samplers.py:187-188), last row out
+                row_count = self._i32([int(n) + step + 1 for n in n_prefix])
+                L.check(lib.valle_cfg_combine_last(L.ptr(hist[0]), L.ptr(hist[1]), ld, V, L.ptr(row_start), L.ptr(row_count), B,
+                                                   float(cfg_strength), float(cfg_rescale), L.ptr(last), ld, stream))
                 if return_logits:
                     all_logits.append(last[:, :V].clone())
                 self._ar_sample_append(last, V, seq, seq_len, [states[0][1][2], states[1][1][2]], stopped, scores, sp, cap,
@@ -382,20 +382,16 @@ class AR_NAR(Base):
 
     def _ar_sample_append(self, logits, V, seq, seq_len, ctx_lens, stopped, scores, sp, cap, step, bump_ctx=False):
         """Sampling of one AR row per utterance from explicit logits + token append (host-driven
-        steps: the prefill row and the CFG path).  prev = the sequence so far (ar_nar.py:804-808)."""
+        steps: the prefill row and the CFG path), one launch (valle_sample_append).  prev = the sequence so far
+        (ar_nar.py:804-808); cached positions grow when the token was run through the stack (bump_ctx)."""
         lib = L.load()
         B = seq.shape[0]
-        prev_off = torch.arange(B, dtype=torch.int32, device=self.device) * cap
         ids = torch.empty(B, dtype=torch.int32, device=self.device)
         sp.offset = step
-        L.check(lib.valle_sample(L.ptr(logits), logits.shape[1], V, B, None, None, L.ptr(seq), L.ptr(prev_off),
-                                 L.ptr(seq_len), 0, C.byref(sp), L.ptr(ids), L.ptr(scores), L.stream_ptr(self.device)))
-        seq.scatter_(1, seq_len.long()[:, None].clamp_(max=cap - 1), ids[:, None])
-        seq_len += 1
-        stopped |= (ids == self.stop_token).int()
-        if bump_ctx:                      # cached positions grow when a token was run through the stack
-            for c in ctx_lens:
-                c += 1
+        ctx = [L.ptr(c) for c in ctx_lens] if bump_ctx else []
+        ctx += [None] * (2 - len(ctx))
+        L.check(lib.valle_sample_append(L.ptr(logits), logits.stride(0), V, B, C.byref(sp), L.ptr(seq), cap, L.ptr(seq_len),
+                                        ctx[0], ctx[1], L.ptr(stopped), L.ptr(ids), L.ptr(scores), L.stream_ptr(self.device)))
 
     # ----------------------------------------------------------------------------------- NAR
     def forward_nar(self, task_list=None, phns_list=None, proms_list=None, resps_list=None, lang_list=None,
@@ -457,17 +453,24 @@ class AR_NAR(Base):
         row_item = np.repeat(np.arange(B, dtype=np.int32), counts)
         row_in = np.concatenate([np.arange(c, dtype=np.int32) for c in counts])
         ri, rn, poff, plen, known_d = self._upload_i32(row_item, row_in, off[:-1], counts, known)
-        base = torch.tensor([self._off[f"resp{l + 1}"] for l in range(n_lv - 1)], dtype=torch.int32, device=self.device)
-        resp_idx = torch.full((total, 8), -1, dtype=torch.int32, device=self.device)           # embedding rows of the codes so far
-        resp_idx[:, :level0] = known_d.view(total, level0) + base[None, :level0]
-        cols = [known_d.view(total, level0)[:, l].contiguous() for l in range(level0)]         # int32 codes per level
+        lib, stream = L.load(), L.stream_ptr(self.device)
+        bases = [self._off[f"resp{l + 1}"] for l in range(n_lv - 1)]
+        # integer tables patched by valle_scatter_cols: resp_idx = embedding rows of the codes so far, flat = the codes
+        # themselves (int64, what the call returns), prev_col = the newest level (the sampler's `prev`)
+        resp_idx = torch.full((total, 8), -1, dtype=torch.int32, device=self.device)
+        flat = torch.empty((total, levels[-1] + 1), dtype=torch.int64, device=self.device)
+        prev_col = torch.empty(total, dtype=torch.int32, device=self.device)
+        for l in range(level0):
+            L.check(lib.valle_scatter_cols(L.ptr(resp_idx), 0, 8, None, L.ptr(known_d), level0, total, l, l, 1, bases[l] if l < n_lv - 1 else 0, stream))
+        L.check(lib.valle_scatter_cols(L.ptr(flat), 1, flat.shape[1], None, L.ptr(known_d), level0, total, 0, 0, level0, 0, stream))
+        L.check(lib.valle_scatter_cols(L.ptr(prev_col), 0, 1, None, L.ptr(known_d), level0, total, 0, level0 - 1, 1, 0, stream))
         for n, q in enumerate(levels):
             plan, rows, dev = plans.pop(n)
             def patch(d):                                                                      # the codes decoded since planning
-                if self.sum_resp_levels:
-                    d[0][d[3].long(), :q] = resp_idx[:, :q]                                    # sum of levels < q
-                else:
-                    d[0][d[3].long(), 0] = resp_idx[:, q - 1]                                  # level q - 1 alone (base.py:169-173)
+                if self.sum_resp_levels:                                                       # sum of levels < q
+                    L.check(lib.valle_scatter_cols(L.ptr(d[0]), 0, 8, L.ptr(d[3]), L.ptr(resp_idx), 8, total, 0, 0, q, 0, stream))
+                else:                                                                          # level q - 1 alone (base.py:169-173)
+                    L.check(lib.valle_scatter_cols(L.ptr(d[0]), 0, 8, L.ptr(d[3]), L.ptr(resp_idx), 8, total, 0, q - 1, 1, 0, stream))
             patch(dev)
             logits = self.forward_dense(plan, rows, dev=dev)
             prepare(n + 1)
@@ -478,11 +481,11 @@ class AR_NAR(Base):
                 null = self.forward_dense(nplan, nrows, dev=ndev)
                 self.cfg_combine(logits, null, V, off, cfg_strength, cfg_rescale)
             sp.offset = 1000 + n
-            ids, _ = self.sample_rows(logits, V, off, None, nar_mode=1, params=sp, dev=(ri, rn, cols[-1], poff, plen))
-            cols.append(ids.contiguous())
+            ids, _ = self.sample_rows(logits, V, off, None, nar_mode=1, params=sp, dev=(ri, rn, prev_col, poff, plen))
+            prev_col = ids
+            L.check(lib.valle_scatter_cols(L.ptr(flat), 1, flat.shape[1], None, L.ptr(ids), 1, total, q, 0, 1, 0, stream))
             if q < n_lv - 1:
-                resp_idx[:, q] = ids + base[q]
-        flat = torch.stack(cols, dim=1).long()                                                 # (total, levels) on the device
+                L.check(lib.valle_scatter_cols(L.ptr(resp_idx), 0, 8, None, L.ptr(ids), 1, total, q, 0, 1, bases[q], stream))
         return [flat[off[i]:off[i + 1]] for i in range(B)]
 
     # ------------------------------------------------------------------------------- NAR-len
@@ -520,6 +523,7 @@ class AR_NAR(Base):
         codes = torch.full((total,), self.mask_token, dtype=torch.int32, device=dev)
         scores = torch.ones(total, dtype=torch.float32, device=dev)
         is_masked = torch.empty(total, dtype=torch.uint8, device=dev)
+        prev_codes = torch.empty(total, dtype=torch.int32, device=dev)
         null_text = self._null_text(phns_list)
         V = self.cls_tokens[self.cls_names.index("NAR:0:0")]
         stream = L.stream_ptr(dev)
@@ -534,13 +538,11 @@ class AR_NAR(Base):
         plan = self.plan(phns_list, lang_list, proms_list, zeros, 0, timestep=True)
         rows, roff = self.tail_rows(plan, lens)
         pdev = self.upload_plan(plan, rows)
-        prow = pdev[3].long()
         resp_base = self._off[f"resp{self.emb_names.index('NAR:0:0')}"]
         if cfg_strength > 0:
             nplan = self.plan(null_text, lang_list, None, zeros, 0, timestep=True)
             nrows, _ = self.tail_rows(nplan, lens)
             ndev = self.upload_plan(nplan, nrows)
-            nrow = ndev[3].long()
         counts = np.diff(roff)
         ri, rn, poff, plen = self._upload_i32(np.repeat(np.arange(B, dtype=np.int32), counts),
                                               np.concatenate([np.arange(c, dtype=np.int32) for c in counts]), roff[:-1], counts)
@@ -548,14 +550,14 @@ class AR_NAR(Base):
             noise_p = math.cos(t * math.pi * 0.5)                               # float32 timestep, as the reference
             mask_p = noise_p + (1.0 / (max_steps * 2) if remasking else 0)
             ks = self._i32([clamp(int(mask_p * n), 1, n - step) for n in lens])  # ar_nar.py:358
-            prev_codes = codes.clone()
+            L.check(lib.valle_scatter_cols(L.ptr(prev_codes), 0, 1, None, L.ptr(codes), 1, total, 0, 0, 1, 0, stream))   # the step's `prev`
             L.check(lib.valle_mask_lowest(L.ptr(scores), L.ptr(codes), L.ptr(is_masked), L.ptr(off_d), L.ptr(ks), B,
                                           max(lens), self.mask_token, stream))
             temp = temperature * (1.0 - float(t)) if annealed else temperature
-            pdev[0][prow, 0] = codes + resp_base
+            L.check(lib.valle_scatter_cols(L.ptr(pdev[0]), 0, 8, L.ptr(pdev[3]), L.ptr(codes), 1, total, 0, 0, 1, resp_base, stream))
             logits = self.forward_dense(plan, rows, dev=pdev)
             if cfg_strength > 0:
-                ndev[0][nrow, 0] = codes + resp_base
+                L.check(lib.valle_scatter_cols(L.ptr(ndev[0]), 0, 8, L.ptr(ndev[3]), L.ptr(codes), 1, total, 0, 0, 1, resp_base, stream))
                 null = self.forward_dense(nplan, nrows, dev=ndev)
                 self.cfg_combine(logits, null, V, roff, cfg_strength, cfg_rescale)
             sdev = (ri, rn, prev_codes, poff, plen)
@@ -570,7 +572,7 @@ class AR_NAR(Base):
             _, sc = self.sample_rows(logits, V, roff, None, nar_mode=1, params=sp2, dev=sdev)
             if trace is not None:
                 trace.append((ids.clone(), sc.clone()))
-            codes = torch.where(is_masked.bool(), ids, codes)                  # ar_nar.py:457
-            scores = torch.where(is_masked.bool(), sc, torch.ones_like(sc)) if masked_only else sc   # ar_nar.py:459-462
-        codes = codes.to(torch.int16)
+            L.check(lib.valle_narlen_commit(L.ptr(codes), L.ptr(scores), L.ptr(is_masked), L.ptr(ids), L.ptr(sc), total,
+                                            1 if masked_only else 0, stream))                  # ar_nar.py:457-462
+        codes = codes.to(torch.int16)              # the reference's dtype for this result (ar_nar.py:457)
         return [codes[off[i]:off[i + 1]] for i in range(B)]

@@ -203,10 +203,12 @@ class Base:
         for l in range(self.n_layers):
             p = f"model.layers.{l}."
             wq, wk, wv = (sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv")
-            b[f"qkv{l}"] = torch.cat((wq[perm], wk[perm], wv)).to(dev, dt).contiguous()
+            host = {"qkv": torch.cat((wq[perm], wk[perm], wv)).to(dt)}          # host copies in the storage dtype
+            b[f"qkv{l}"] = host["qkv"].to(dev).contiguous()
             b[f"o{l}"] = sd[p + "self_attn.o_proj.weight"].to(dev, dt).contiguous()
             gu = torch.stack((sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]), dim=1).reshape(2 * ff, d)
-            b[f"gu{l}"] = gu.to(dev, dt).contiguous()
+            host["gu"] = gu.to(dt)
+            b[f"gu{l}"] = host["gu"].to(dev).contiguous()
             b[f"down{l}"] = sd[p + "mlp.down_proj.weight"].to(dev, dt).contiguous()
             b[f"ln1_{l}"] = sd[p + "input_layernorm.weight"].to(dev, dt).contiguous()
             b[f"ln2_{l}"] = sd[p + "post_attention_layernorm.weight"].to(dev, dt).contiguous()
@@ -217,8 +219,10 @@ class Base:
                     packed[j] = b[f"p_{n}{l}"].data_ptr()
                 # norm weight folded in (product in fp32 of the bf16-rounded factors, rounded to bf16 once)
                 for j, (n, ln) in enumerate((("qkv", "ln1_"), ("gu", "ln2_"))):
-                    folded = (b[f"{n}{l}"].float() * b[f"{ln}{l}"].float()[None, :]).to(dt)
-                    b[f"pn_{n}{l}"] = pack_stream_order(folded)
+                    # (on the host: weight preparation runs once and leaves no torch arithmetic kernel on the device)
+                    ln_host = sd[p + ("input_layernorm.weight" if ln == "ln1_" else "post_attention_layernorm.weight")].to(dt)
+                    folded = (host[n].float() * ln_host.float()[None, :]).to(dt)
+                    b[f"pn_{n}{l}"] = pack_stream_order(folded).to(dev)
                     packed[2 + j] = b[f"pn_{n}{l}"].data_ptr()
             layers[l] = L.LayerWeights(b[f"ln1_{l}"].data_ptr(), b[f"qkv{l}"].data_ptr(), b[f"o{l}"].data_ptr(),
                                        b[f"ln2_{l}"].data_ptr(), b[f"gu{l}"].data_ptr(), b[f"down{l}"].data_ptr(), *packed)
@@ -237,7 +241,8 @@ class Base:
             hn[k] = self.cls_tokens[k]
             hpn[k] = None
             if dt == torch.bfloat16 and k == 0:      # the AR head is the one the decode loop streams
-                b[f"hpn{k}"] = pack_stream_order((b[f"hw{k}"].float() * b["norm"].float()[None, :]).to(dt))
+                hw_host = sd[f"classifiers.proj.{k}.weight"].to(dt)
+                b[f"hpn{k}"] = pack_stream_order((hw_host.float() * sd["model.norm.weight"].to(dt).float()[None, :]).to(dt)).to(dev)
                 hpn[k] = b[f"hpn{k}"].data_ptr()
         cfg = L.Config(d, H, self.n_layers, ff, L.dtype_code(dt), 1e-6, self.max_position_embeddings)
         handle = C.c_void_p()
