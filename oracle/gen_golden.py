@@ -46,7 +46,7 @@ import ref_harness as rh  # noqa: E402
 sys.path.insert(0, str(ROOT / "tests"))
 import model_configs as vcfg  # noqa: E402  (tests/model_configs.py: the reduced-size configurations)
 from vall_e_amd.synth import synth_batch, synth_utterance, QNT_ENC_PHONEME_IDS  # noqa: E402
-from vall_e_amd.weights import synth_state_dict  # noqa: E402
+from vall_e_amd.weights import synth_state_dict, synth_lora_state_dict  # noqa: E402
 
 GOLD = ROOT / "tests" / "golden"
 WEIGHT_SEED = 1234
@@ -95,8 +95,12 @@ _models = {}
 
 def get_ref_model(kind, dtype=torch.float32, **synth_kw):
     key = (kind, dtype, tuple(sorted(synth_kw.items())))
+    ref_cfg = rh.load_reference().cfg
     if key in _models:
-        return _models[key]
+        ref_cfg.loras = _models[key][2]
+        return _models[key][:2]
+    synth_kw = dict(synth_kw)
+    lora = synth_kw.pop("lora", None)              # (rank, alpha, rvq_levels): the reference's LoRA path, engines/__init__.py:102-103
     mcfg = {"full": vcfg.repo_default_model, "tiny": vcfg.tiny_model, "tiny_len": vcfg.tiny_len_model,
             "tiny_nc": vcfg.tiny_nc_model, "tiny_tone": vcfg.tiny_tone_model, "tiny_upi": vcfg.tiny_upi_model, "tiny_nobias": vcfg.tiny_nobias_model, "tiny_nc_upi": vcfg.tiny_nc_upi_model, "tiny_nosum": vcfg.tiny_nosum_model, "tiny_sumprom": vcfg.tiny_sumprom_model,
             "half2": lambda: vcfg.tiny_model(dim=512, heads=8), "s075_2": lambda: vcfg.tiny_model(dim=768, heads=12)}[kind]()
@@ -109,12 +113,26 @@ def get_ref_model(kind, dtype=torch.float32, **synth_kw):
     assert model.proms_emb.sums == (mcfg.experimental.audio_embedding_sums in (True, "prom"))
     assert model.noncausal_masks == mcfg.experimental.noncausal_masks
     assert model.unified_position_ids == mcfg.experimental.unified_position_ids
-    synth_kw = dict(synth_kw)
     sd = synth_state_dict(mcfg, synth_kw.pop("weight_seed", WEIGHT_SEED), **synth_kw)
-    missing = model.load_state_dict(sd, strict=True)
+    loras = []
+    if lora is None:
+        model.load_state_dict(sd, strict=True)
+    else:
+        from vall_e.models.lora import apply_lora, LoRALinear
+        from vall_e.config import LoRA
+        rank, alpha, levels = lora
+        # the replacement linears are freshly initialised (lora.py:79-85 copies no weight): as in engines/__init__.py:102-103
+        # vs :218-262, the LoRA modules go in first and the base + LoRA state dicts are loaded after
+        model.model = apply_lora(model.model, rank=rank, alpha=alpha, policy=model.config.lora_policy)
+        sd.update(synth_lora_state_dict(mcfg, rank))
+        model.load_state_dict(sd, strict=True)
+        n = sum(isinstance(m, LoRALinear) for m in model.modules())
+        assert n == 6 * mcfg.layers, n                                  # q, v, o, gate, up, down per layer (config.py:519-530)
+        loras = [LoRA(rank=rank, alpha=alpha, rvq_levels=list(levels), training=False)]
+    ref_cfg.loras = loras
     model = model.to(dtype).eval()
     _models.clear()  # keep one model in memory at a time
-    _models[key] = (model, mcfg)
+    _models[key] = (model, mcfg, loras)
     return model, mcfg
 
 
@@ -782,6 +800,28 @@ def scen_long():
     ar_nar_scenario("tiny_long", "tiny", mk, 301, steps=320, min_gap=4e-5, nar=False)
 
 
+def scen_tiny_lora():
+    """Per-level LoRA switching (models/lora.py:183-191 via ar_nar.py:539-540, :619-620): synthetic LoRA tensors on the six
+    targeted linears of every layer, rvq_levels [0, 2] -> the AR pass and NAR level 2 run adapted, the other levels plain.
+    tiny_lora_all: rvq_levels [] (every level adapted).  tiny_lora_off: the same call with use_lora=False, which must
+    reproduce the plain model's codes (asserted here against a run without any LoRA)."""
+    mk = lambda s: synth_batch(s, 2, n_phn=10, n_prom=16, ragged=True)
+    rank, alpha = 4, 8
+    ar_nar_scenario("tiny_lora", "tiny", mk, 81, steps=12, model_kw=dict(lora=(rank, alpha, (0, 2))))
+    seed = int(np.load(GOLD / "tiny_lora.npz")["input_seed"])
+    same = lambda s: mk(seed)
+    ar_nar_scenario("tiny_lora_all", "tiny", same, seed, steps=12, min_gap=0.0, model_kw=dict(lora=(rank, alpha, ())))
+    ar_nar_scenario("tiny_lora_off", "tiny", same, seed, steps=12, min_gap=0.0, model_kw=dict(lora=(rank, alpha, (0, 2))),
+                    ar_kw=dict(use_lora=False), nar_kw=dict(use_lora=False))
+    ar_nar_scenario("tiny_lora_plain", "tiny", same, seed, steps=12, min_gap=0.0)
+    g = {n: np.load(GOLD / f"tiny_lora{n}.npz") for n in ("", "_all", "_off", "_plain")}
+    for i in range(2):
+        assert (g["_off"][f"nar_codes_{i}"] == g["_plain"][f"nar_codes_{i}"]).all()
+    assert any((g[""][f"ar_codes_{i}"] != g["_plain"][f"ar_codes_{i}"]).any() for i in range(2)), "LoRA changed nothing"
+    (GOLD / "tiny_lora_plain.npz").unlink()
+    print("  [tiny_lora] use_lora=False == no LoRA; adapted codes differ from plain")
+
+
 def scen_full_b3():
     mk = lambda s: synth_batch(s, 3, n_phn=30, n_prom=60, ragged=True)
     ar_nar_scenario("full_b3", "full", mk, 61, steps=12)
@@ -832,6 +872,7 @@ SCENARIOS = {
     "tiny_raw_text": scen_tiny_raw_text,
     "tiny_tone": scen_tiny_tone,
     "tiny_unified_positions": scen_tiny_unified_positions,
+    "tiny_lora": scen_tiny_lora,
     "full_b1": scen_full_b1,
     "long": scen_long,
     "full_b3": scen_full_b3,

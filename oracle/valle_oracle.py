@@ -321,6 +321,30 @@ class Oracle:
         if threads:
             torch.set_num_threads(threads)
 
+    # -- LoRA (models/lora.py:19-75; switched per RVQ level, lora.py:183-191 via ar_nar.py:268-269, :539-540, :619-620) --
+    lora = None          # (tensors in the reference's names, rank, alpha, rvq_levels)
+    lora_on = False
+    use_lora = None      # the call's override
+
+    def load_lora(self, tensors, rank, alpha, rvq_levels=()):
+        self.lora = ({k: v.to(self.dtype) for k, v in tensors.items()}, rank, alpha, tuple(rvq_levels))
+
+    def set_lora_level(self, level):
+        if self.lora is None:
+            self.lora_on = False
+        elif self.use_lora is not None:
+            self.lora_on = bool(self.use_lora)
+        else:
+            self.lora_on = (not self.lora[3]) or (level in self.lora[3])        # config.py:556-559
+
+    def _lin(self, x, name):
+        """LoRALinear.forward (lora.py:67-75): the base product plus (x A^T B^T) * alpha / rank when switched on."""
+        r = F.linear(x, self.w[name + ".weight"])
+        if self.lora_on and (name + ".lora_A") in self.lora[0]:
+            t, rank, alpha, _ = self.lora
+            r = r + (x @ t[name + ".lora_A"].transpose(0, 1) @ t[name + ".lora_B"].transpose(0, 1)) * (alpha / rank)
+        return r
+
     # -- embeddings (base.py:774-922) ---------------------------------------------
     tones = None     # tone_list of the current call (every pass of a call carries the same list)
 
@@ -411,9 +435,9 @@ class Oracle:
         for l in range(self.L):
             p = f"model.layers.{l}."
             h = self.rms_norm(x, self.w[p + "input_layernorm.weight"])
-            q = F.linear(h, self.w[p + "self_attn.q_proj.weight"]).view(-1, self.H, self.Dh)
-            k = F.linear(h, self.w[p + "self_attn.k_proj.weight"]).view(-1, self.H, self.Dh)
-            v = F.linear(h, self.w[p + "self_attn.v_proj.weight"]).view(-1, self.H, self.Dh)
+            q = self._lin(h, p + "self_attn.q_proj").view(-1, self.H, self.Dh)
+            k = self._lin(h, p + "self_attn.k_proj").view(-1, self.H, self.Dh)
+            v = self._lin(h, p + "self_attn.v_proj").view(-1, self.H, self.Dh)
             q, k = self._rot(q, cos, sin), self._rot(k, cos, sin)
             outs = []
             for b, n in enumerate(lens):
@@ -436,11 +460,11 @@ class Oracle:
                 att = torch.softmax(att.float(), dim=-1).to(qb.dtype)
                 outs.append((att @ vb).transpose(0, 1).reshape(n, self.d))
             a = torch.cat(outs, dim=0)
-            x = x + F.linear(a, self.w[p + "self_attn.o_proj.weight"])
+            x = x + self._lin(a, p + "self_attn.o_proj")
             h = self.rms_norm(x, self.w[p + "post_attention_layernorm.weight"])
-            g = F.gelu(F.linear(h, self.w[p + "mlp.gate_proj.weight"]))
-            u = F.linear(h, self.w[p + "mlp.up_proj.weight"])
-            x = x + F.linear(g * u, self.w[p + "mlp.down_proj.weight"])
+            g = F.gelu(self._lin(h, p + "mlp.gate_proj"))
+            u = self._lin(h, p + "mlp.up_proj")
+            x = x + self._lin(g * u, p + "mlp.down_proj")
             if layer_probe is not None and l == 0:
                 layer_probe["layer0"] = x
         x = self.rms_norm(x, self.w["model.norm.weight"])
@@ -481,12 +505,14 @@ class Oracle:
                               unified_pos=self.unified_pos, tone=None if tones is None else tones[i]) for i in range(B)]
 
     # -- duration prediction (ar_nar.py:640-692, len task) ------------------------------------
-    def predict_len(self, phns, proms, langs, *, return_logits=False):
+    def predict_len(self, phns, proms, langs, *, return_logits=False, use_lora=None):
         """<= 10 greedy steps over the 11-token ``len`` head, sequences seeded with digit 0.  Like the
         reference it keeps appending to utterances that already stopped until ALL have, and the final
         integer drops every stop token (10) but keeps digits that came after one."""
         B = len(phns)
         stop = 10
+        self.use_lora = use_lora
+        self.set_lora_level(0)                                           # ar_nar.py:619-620 (the len task runs behind it)
         seqs = [torch.tensor([0]) for _ in range(B)]
         stopped = [False] * B
         kept = []
@@ -521,6 +547,8 @@ class Oracle:
         input_prompt_prefix = kw.pop("input_prompt_prefix", False)
         refine_on_stop = kw.pop("refine_on_stop", False)
         B = len(phns)
+        self.use_lora = kw.pop("use_lora", None)
+        self.set_lora_level(0)                                           # ar_nar.py:619-620
         seqs = [torch.zeros(0, dtype=torch.int64) for _ in range(B)]
         start = [0] * B
         if input_prompt_prefix:                                              # ar_nar.py:727-729: the prompt's level-0 codes
@@ -589,6 +617,7 @@ class Oracle:
         max_levels = kw.get("max_levels", 0) or (self.cfg.max_levels - 1)
         cfg_strength = kw.get("cfg_strength", 0.0)
         cfg_rescale = kw.pop("cfg_rescale", 0.7)
+        self.use_lora = kw.pop("use_lora", None)
         B = len(resps)
         prev = [r[:, None] if r.dim() == 1 else r for r in resps]
         prev = [p.long() for p in prev]
@@ -601,6 +630,7 @@ class Oracle:
             # quirk: the level loop hands only phns_list to inputs() (ar_nar.py:544-551), so raw text (text_list) is
             # absent from the conditional pass of every NAR level; the null pass of the guidance does get it (:560-562)
             cond = [None if isinstance(p, RawText) else p for p in phns]
+            self.set_lora_level(level)                                   # ar_nar.py:539-540
             logits = self.forward(self._plans(cond, langs, proms, prev, level), rows=R)
             if cfg_strength > 0:
                 null = self.forward(self._plans(null_phn, langs, None, prev, level), rows=R)
@@ -632,6 +662,8 @@ class Oracle:
         if prefix_context is not None:                                   # ar_nar.py:321-325, :391-392
             phns = [torch.cat([p[:-1].long(), t[1:].long()]) for p, t in zip(prefix_context[0], phns)]
             prefix = [(r if r.dim() == 1 else r[:, 0]).long() for r in prefix_context[1]]
+        self.use_lora = kw.pop("use_lora", None)
+        self.set_lora_level(0)                                           # ar_nar.py:262-269
         resps = [torch.full((n,), self.mask_token, dtype=torch.int64) for n in lens]
         scores = [torch.ones(n, dtype=torch.float32) for n in lens]
         null_phn = [RawText([1, 2]) if isinstance(phns[i], RawText) else torch.tensor([1, 2]) for i in range(B)]

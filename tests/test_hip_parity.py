@@ -251,10 +251,14 @@ def test_full_forward_logits_fp32(gpu_device):
     _probe("full", "full_b1_fwd", *qnt_inputs())
 
 
-def _ar_nar(kind, name, **model_kw):
+def _ar_nar(kind, name, lora=None, **model_kw):
     z = load_golden(name)
     phns, proms, langs = golden_inputs(z)
     m = hip_model(kind, **model_kw)
+    if lora is not None:
+        from vall_e_amd.weights import synth_lora_state_dict
+        rank, alpha, levels = lora
+        m.load_lora(synth_lora_state_dict(model_cfg(kind), rank), rank=rank, alpha=alpha, rvq_levels=levels)
     B = len(phns)
     kw = {k[3:]: float(v) for k, v in z.items() if k.startswith("kw_") and not k.startswith("kw_nar_")}
     if "top_k" in kw:
@@ -291,6 +295,14 @@ def test_tiny_stop_token_and_length_penalty(gpu_device):
 
 def test_tiny_cfg(gpu_device):
     _ar_nar("tiny", "tiny_cfg")
+
+
+def test_tiny_lora_switched_per_level(gpu_device):
+    """Per-level LoRA (reference models/lora.py:183-191 through ar_nar.py:539-540, :619-620), goldens made by the reference
+    with apply_lora + synthetic lora_A / lora_B: rvq_levels [0, 2], every level, and the use_lora=False override."""
+    _ar_nar("tiny", "tiny_lora", lora=(4, 8, (0, 2)))
+    _ar_nar("tiny", "tiny_lora_all", lora=(4, 8, ()))
+    _ar_nar("tiny", "tiny_lora_off", lora=(4, 8, (0, 2)))
 
 
 def test_full_b1_configs0_codes_identical(gpu_device):

@@ -9,6 +9,7 @@ import torch
 
 from conftest import load_golden, golden_inputs, qnt_inputs, model_cfg, synth_weights
 import valle_oracle as vo
+from vall_e_amd.weights import synth_lora_state_dict
 
 
 def make_oracle(kind, dtype=torch.float32, **kw):
@@ -120,10 +121,13 @@ def test_full_forward_probe():
     _probe("full", z, phns, proms, langs)
 
 
-def _ar_nar(kind, name, use_cache=False, **model_kw):
+def _ar_nar(kind, name, use_cache=False, lora=None, **model_kw):
     z = load_golden(name)
     phns, proms, langs = golden_inputs(z)
     o = make_oracle(kind, **model_kw)
+    if lora is not None:
+        rank, alpha, levels = lora
+        o.load_lora(synth_lora_state_dict(model_cfg(kind), rank), rank, alpha, levels)
     B = len(phns)
     kw = {k[3:]: float(v) for k, v in z.items() if k.startswith("kw_") and not k.startswith("kw_nar_")}
     if "top_k" in kw:
@@ -166,6 +170,19 @@ def test_tiny_stop_token_and_length_penalty():
 
 def test_tiny_cfg():
     _ar_nar("tiny", "tiny_cfg")
+
+
+def test_tiny_lora_switched_per_level():
+    """models/lora.py:183-191 through ar_nar.py:539-540, :619-620: rvq_levels [0, 2] adapts the AR pass and NAR level 2 only;
+    [] adapts every level; use_lora=False gives the plain model back."""
+    _ar_nar("tiny", "tiny_lora", lora=(4, 8, (0, 2)))
+    _ar_nar("tiny", "tiny_lora", lora=(4, 8, (0, 2)), use_cache=True)
+    _ar_nar("tiny", "tiny_lora_all", lora=(4, 8, ()))
+    _ar_nar("tiny", "tiny_lora_off", lora=(4, 8, (0, 2)))
+    _ar_nar("tiny", "tiny_lora_off")                       # == a model with no LoRA at all
+    a, b = load_golden("tiny_lora"), load_golden("tiny_lora_all")
+    assert (a["ar_codes_0"] == b["ar_codes_0"]).all()                                  # level 0 is adapted in both
+    assert (a["nar_codes_0"][:, 1] != b["nar_codes_0"][:, 1]).any()                    # level 1 is not, in the first
 
 
 def _narlen(kind, name, **kw):

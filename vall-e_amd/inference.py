@@ -111,8 +111,6 @@ class TTS:
     reference's parameter names -> tensors (random-init synthetic weights if omitted)."""
 
     def __init__(self, config=None, lora=None, device=None, amp=None, dtype=None, attention=None, state_dict=None, seed=1234):
-        if lora is not None:
-            raise NotImplementedError("LoRA is outside the built path")
         if attention not in (None, "auto", "valle_hip"):
             raise NotImplementedError(f"attention backend {attention!r}: the HIP path has one attention implementation")
         if isinstance(config, (str, Path)):
@@ -133,6 +131,27 @@ class TTS:
             from .weights import synth_state_dict
             state_dict = synth_state_dict(self.config, seed)
         self.model = get_model(self.config).load_state_dict(state_dict).to(self.device, self.dtype)
+        if lora is not None:                                               # inference.py:38-45, engines/__init__.py:250-262
+            self.load_lora(lora)
+
+    def load_lora(self, lora):
+        """A LoRA weights file as Engines.export / extract_lora write it (export.py:190-222: tensors under ``lora`` or
+        ``module``, ``config`` = the LoRA dataclass: rank, alpha, rvq_levels), or a dict
+        ``{"lora": tensors, "config": {...}}``."""
+        if isinstance(lora, (str, Path)):
+            from .utils.io import torch_load
+            lora = torch_load(lora)
+        tensors = lora.get("lora") or lora.get("module")
+        conf = lora.get("config") or {}
+        self.model.load_lora(tensors, rank=conf.get("rank", 128), alpha=conf.get("alpha", 128), rvq_levels=conf.get("rvq_levels", []))
+
+    def enable_lora(self, enabled=True):
+        """inference.py:104-109.  As in the reference, every generation call switches the LoRA again per RVQ level
+        (``use_lora=`` overrides), so this only sets the state between calls."""
+        self.model._call_state.lora_on = bool(enabled) and self.model._lora is not None
+
+    def disable_lora(self):
+        return self.enable_lora(False)
 
     # ---------------------------------------------------------------- text front end (ids only)
     LANG_SYMMAP = {"en": 0, "ja": 1, "de": 2, "fr": 3, "zh": 4, "ko": 5}     # data.py:650-658
@@ -179,7 +198,7 @@ class TTS:
         seed = sampling_kwargs.pop("seed", None)              # None: a fresh one per call, as the reference does
         if seed is None:
             seed = derive_seed(None)
-        for k in ("input_prompt_length", "tqdm", "use_lora", "dtype", "amp", "voice_convert", "split_text_by"):
+        for k in ("input_prompt_length", "tqdm", "dtype", "amp", "voice_convert", "split_text_by"):
             sampling_kwargs.pop(k, None)
         phonemize = sampling_kwargs.pop("phonemize", True)     # False: lines are raw-text ids, sent as text_list (inference.py:518-519)
         modality = self.modality(sampling_kwargs.pop("modality", "auto"))
@@ -237,7 +256,7 @@ class TTS:
         seed = sampling_kwargs.pop("seed", None)              # inference.py:315: set_seed per chunk; None = a fresh seed
         if seed is None:
             seed = derive_seed(None)
-        for k in ("input_prompt_length", "tqdm", "use_lora", "dtype", "amp"):
+        for k in ("input_prompt_length", "tqdm", "dtype", "amp"):
             sampling_kwargs.pop(k, None)
         duration_padding = sampling_kwargs.pop("duration_padding", 1.05)
         n = len(texts)

@@ -71,11 +71,19 @@ class AR_NAR(Base):
         # tone tokens enter a sequence only with the "tone" capability (base.py:623-624); every pass the reference plans
         # for this call -- conditional, null, len -- carries the same list, so it is kept for the duration of the call
         self._call_state.tones = tone_list if "tone" in self.capabilities else None
+        self._call_state.use_lora = use_lora
+        self._call_state.lora_on = False
         try:
             return self._forward(task_list, phns_list, proms_list, resps_list, lang_list, len_list, text_list, training,
                                  **sampling_kwargs)
         finally:
             self._call_state.tones = None
+            self._call_state.lora_on = False
+
+    def _set_lora_level(self, level):
+        """enable_lora(self, cfg.lora.active_level(level) if use_lora is None else use_lora) of the reference's three
+        generation loops: picks the weight set of the passes that follow."""
+        self._call_state.lora_on = self.lora_active_level(level, getattr(self._call_state, "use_lora", None))
 
     def _forward(self, task_list, phns_list, proms_list, resps_list, lang_list, len_list, text_list, training, **sampling_kwargs):
         if text_list is not None and phns_list is None:                       # raw text in place of phonemes (base.py:609-610):
@@ -136,10 +144,15 @@ class AR_NAR(Base):
     def forward_ar(self, task_list=None, phns_list=None, proms_list=None, resps_list=None, lang_list=None,
                    disable_tqdm=False, use_lora=None, **sampling_kwargs):
         """Level-0 autoregressive loop, ar_nar.py:588-890 (tts task); duration prediction for the len task."""
-        if task_list is not None and task_list[0] == "len":                     # ar_nar.py:640
+        if use_lora is not None:                                                # a direct call (forward() keeps it in the call state)
+            self._call_state.use_lora = use_lora
+        if task_list is not None and task_list[0] == "len":                     # ar_nar.py:640 (behind the LoRA switch of :619-620)
+            self._prepare()
+            self._set_lora_level(0)
             return self.forward_len(phns_list=phns_list, proms_list=proms_list, lang_list=lang_list,
                                     return_logits=sampling_kwargs.get("return_logits", False))
         self._prepare()
+        self._set_lora_level(0)                                               # ar_nar.py:619-620
         lib = L.load()
         kw = convert_kwargs(dict(sampling_kwargs), "ar_")
         cfg_strength = kw.get("cfg_strength", 0.0)
@@ -397,6 +410,8 @@ class AR_NAR(Base):
     def forward_nar(self, task_list=None, phns_list=None, proms_list=None, resps_list=None, lang_list=None,
                     len_list=None, disable_tqdm=False, use_lora=None, **sampling_kwargs):
         """Levels 1..max_levels, one dense pass per level (ar_nar.py:466-586)."""
+        if use_lora is not None:
+            self._call_state.use_lora = use_lora
         if len_list is not None:                                              # ar_nar.py:485-496
             resps_list = self.forward_nar_masked(task_list=task_list, phns_list=phns_list, proms_list=proms_list,
                                                  resps_list=resps_list, lang_list=lang_list, len_list=len_list,
@@ -465,6 +480,7 @@ class AR_NAR(Base):
         L.check(lib.valle_scatter_cols(L.ptr(flat), 1, flat.shape[1], None, L.ptr(known_d), level0, total, 0, 0, level0, 0, stream))
         L.check(lib.valle_scatter_cols(L.ptr(prev_col), 0, 1, None, L.ptr(known_d), level0, total, 0, level0 - 1, 1, 0, stream))
         for n, q in enumerate(levels):
+            self._set_lora_level(q)                                                            # ar_nar.py:539-540
             plan, rows, dev = plans.pop(n)
             def patch(d):                                                                      # the codes decoded since planning
                 if self.sum_resp_levels:                                                       # sum of levels < q
@@ -493,6 +509,9 @@ class AR_NAR(Base):
                            len_list=None, quant_levels=None, disable_tqdm=False, use_lora=None, **sampling_kwargs):
         """Level-0 iterative demasking (ar_nar.py:233-464)."""
         self._prepare()
+        if use_lora is not None:
+            self._call_state.use_lora = use_lora
+        self._set_lora_level(0 if quant_levels is None else quant_levels[0])  # ar_nar.py:262-269
         lib = L.load()
         kw = convert_kwargs(dict(sampling_kwargs), "ar_")                     # (sic) ar_nar.py:282
         min_length = kw.pop("min_duration", 1)

@@ -106,10 +106,11 @@ class Base:
         self.dtype = torch.float32
         self._off, self._table_order = self._table_offsets()
         self._sd = None
-        self._handle = None
+        self._handles = {}                         # False: base weights, True: LoRA merged (when one is loaded)
+        self._lora = None                          # (tensors, rank, alpha, rvq_levels)
         self._bufs = {}
         self._ws = None
-        self._call_state = threading.local()       # per-thread state of the call in flight (tone list)
+        self._call_state = threading.local()       # per-thread state of the call in flight (tone list, LoRA on/off)
         self._keep = []
 
     # ------------------------------------------------------------- nn.Module-ish surface
@@ -149,9 +150,55 @@ class Base:
         return self
 
     def _release(self):
-        if self._handle is not None:
-            L.load().valle_model_destroy(self._handle)
-        self._handle, self._bufs, self._ws, self._keep = None, {}, None, []
+        for h in self._handles.values():
+            L.load().valle_model_destroy(h)
+        self._handles, self._bufs, self._ws, self._keep = {}, {}, None, []
+
+    @property
+    def _handle(self):
+        """The model descriptor of the call in flight: LoRA-merged weights when a LoRA is loaded and switched on for this
+        pass (AR_NAR sets it per RVQ level, reference models/lora.py:183-191 through ar_nar.py:268-269, :539-540, :619-620)."""
+        if not self._handles:
+            return None
+        on = bool(getattr(self._call_state, "lora_on", False)) and True in self._handles
+        return self._handles[on]
+
+    # ------------------------------------------------------------------------------ LoRA
+    def load_lora(self, lora_state_dict, rank, alpha, rvq_levels=()):
+        """LoRA weights in the reference's names (``model.layers.N.<linear>.lora_A`` (rank, in) / ``.lora_B`` (out, rank),
+        models/lora.py:19-75; targets per config.py:519-530: self_attn and mlp linears except k_proj).  The adapted
+        linears get a second set of device weights W + (alpha / rank) B A; ``rvq_levels`` (config.py:547, :556-559)
+        lists the RVQ levels whose passes use it (empty: all)."""
+        t = {k: v.detach().to("cpu", torch.float32) for k, v in lora_state_dict.items() if "lora_" in k}
+        if not t:
+            raise ValueError("no lora_A / lora_B tensors in the state dict")
+        for k in t:
+            if not (k.startswith("model.layers.") and ("self_attn." in k or "mlp." in k)):
+                raise NotImplementedError(f"{k}: LoRA on modules other than the stack's linears is not built")
+        self._lora = (t, int(rank), float(alpha), tuple(int(x) for x in rvq_levels))
+        self._release()
+        return self
+
+    def lora_active_level(self, level, use_lora=None):
+        """config.py:556-559 ``LoRA.active_level`` with the call's ``use_lora`` override (ar_nar.py:268-269)."""
+        if self._lora is None:
+            return False
+        if use_lora is not None:
+            return bool(use_lora)
+        levels = self._lora[3]
+        return True if not levels else int(level) in levels
+
+    def _merged_lora_sd(self):
+        t, rank, alpha, _ = self._lora
+        sd = dict(self._sd)
+        for ka in [k for k in t if k.endswith(".lora_A")]:
+            base = ka[: -len(".lora_A")]
+            A, Bm = t[ka], t[base + ".lora_B"]
+            W = sd[base + ".weight"]
+            if A.shape != (rank, W.shape[1]) or Bm.shape != (W.shape[0], rank):
+                raise ValueError(f"{base}: lora_A {tuple(A.shape)} / lora_B {tuple(Bm.shape)} do not fit weight {tuple(W.shape)} at rank {rank}")
+            sd[base + ".weight"] = W + (Bm @ A) * (alpha / rank)         # models/lora.py:61-65, merged form of :69-72
+        return sd
 
     def __del__(self):
         try:
@@ -174,28 +221,17 @@ class Base:
             row += 1 if len(spec[key]) == 1 else spec[key][0]
         return off, order
 
-    def _prepare(self):
-        if self._handle is not None:
-            return
-        if self._sd is None:
-            raise RuntimeError("load_state_dict first")
-        if self.device.type != "cuda":
-            raise L.ValleHipError("the HIP path needs a GPU device (model.to('cuda')); there is no CPU fallback")
-        lib = L.load()
-        sd, dev, dt = self._sd, self.device, self.dtype
+    def _build_layers(self, sd, tag=""):
+        """Device copies of the layer weights of state dict ``sd`` in the kernels' layouts (include/valle_hip.h) ->
+        valle_layer_weights array; buffers are kept in self._bufs under ``tag``-prefixed names."""
+        dev, dt = self.device, self.dtype
         d, H, ff = self.d_model, self.n_heads, self.d_model * self.d_ffn
-        off = self._off
-        # concatenated embedding table (row offsets: _table_offsets)
-        tabs = [sd[key].reshape(-1, d) for _, key in self._table_order]
-        b = self._bufs
-        b["emb"] = torch.cat(tabs).to(dev, dt).contiguous()
-        # RoPE table, computed exactly as the reference does (arch/llama.py:118-127): fp32
-        # outer product of positions and inv_freq, then cos / sin
         Dh = d // H
-        inv_freq = 1.0 / (10000.0 ** (torch.arange(0, Dh, 2, dtype=torch.int64).float() / Dh))
-        pos = torch.arange(self.max_position_embeddings, dtype=torch.float32)
-        freqs = (inv_freq[None, :, None] @ pos[None, None, :]).transpose(1, 2)[0]      # (P, Dh/2)
-        b["rope"] = torch.stack((freqs.cos(), freqs.sin()), dim=-1).to(dev).contiguous()  # (P, Dh/2, 2) fp32
+        store = self._bufs
+        class _B(dict):                      # writes go to the shared buffer table under the tag
+            def __setitem__(s_, k, v): store[tag + k] = v
+            def __getitem__(s_, k): return store[tag + k]
+        b = _B()
         # per-head row permutation that makes RoPE pairs adjacent: (0,32,1,33,...)
         perm_head = torch.stack((torch.arange(Dh // 2), torch.arange(Dh // 2) + Dh // 2), dim=1).reshape(-1)
         perm = (torch.arange(H)[:, None] * Dh + perm_head[None, :]).reshape(-1)
@@ -226,6 +262,31 @@ class Base:
                     packed[2 + j] = b[f"pn_{n}{l}"].data_ptr()
             layers[l] = L.LayerWeights(b[f"ln1_{l}"].data_ptr(), b[f"qkv{l}"].data_ptr(), b[f"o{l}"].data_ptr(),
                                        b[f"ln2_{l}"].data_ptr(), b[f"gu{l}"].data_ptr(), b[f"down{l}"].data_ptr(), *packed)
+        return layers
+
+    def _prepare(self):
+        if self._handles:
+            return
+        if self._sd is None:
+            raise RuntimeError("load_state_dict first")
+        if self.device.type != "cuda":
+            raise L.ValleHipError("the HIP path needs a GPU device (model.to('cuda')); there is no CPU fallback")
+        lib = L.load()
+        sd, dev, dt = self._sd, self.device, self.dtype
+        d, H, ff = self.d_model, self.n_heads, self.d_model * self.d_ffn
+        off = self._off
+        # concatenated embedding table (row offsets: _table_offsets)
+        tabs = [sd[key].reshape(-1, d) for _, key in self._table_order]
+        b = self._bufs
+        b["emb"] = torch.cat(tabs).to(dev, dt).contiguous()
+        # RoPE table, computed exactly as the reference does (arch/llama.py:118-127): fp32
+        # outer product of positions and inv_freq, then cos / sin
+        Dh = d // H
+        inv_freq = 1.0 / (10000.0 ** (torch.arange(0, Dh, 2, dtype=torch.int64).float() / Dh))
+        pos = torch.arange(self.max_position_embeddings, dtype=torch.float32)
+        freqs = (inv_freq[None, :, None] @ pos[None, None, :]).transpose(1, 2)[0]      # (P, Dh/2)
+        b["rope"] = torch.stack((freqs.cos(), freqs.sin()), dim=-1).to(dev).contiguous()  # (P, Dh/2, 2) fp32
+        layers = self._build_layers(sd)
         b["norm"] = sd["model.norm.weight"].to(dev, dt).contiguous()
         n_cls = len(self.cls_tokens)
         hw, hb, hn, hpn = (C.c_void_p * n_cls)(), (C.c_void_p * n_cls)(), (C.c_int32 * n_cls)(), (C.c_void_p * n_cls)()
@@ -248,8 +309,16 @@ class Base:
         handle = C.c_void_p()
         L.check(lib.valle_model_create(C.byref(cfg), L.ptr(b["emb"]), L.ptr(b["rope"]), layers, L.ptr(b["norm"]), n_cls,
                                        hw, hb, hn, hpn, C.byref(handle)))
-        self._handle = handle
+        self._handles[False] = handle
         self._keep = [layers, hw, hb, hn, hpn]
+        if self._lora is not None:
+            # second descriptor: same tables, heads and norms, the adapted linears merged (models/lora.py:61-65)
+            layers2 = self._build_layers(self._merged_lora_sd(), tag="lora:")
+            handle2 = C.c_void_p()
+            L.check(lib.valle_model_create(C.byref(cfg), L.ptr(b["emb"]), L.ptr(b["rope"]), layers2, L.ptr(b["norm"]), n_cls,
+                                           hw, hb, hn, hpn, C.byref(handle2)))
+            self._handles[True] = handle2
+            self._keep.append(layers2)
 
     # -------------------------------------------------------------------- sequence planning
     def inputs(self, phns_list=None, text_list=None, proms_list=None, resps_list=None, lang_list=None, tone_list=None,

@@ -122,3 +122,29 @@ def synth_state_dict(cfg: Model, seed: int = 1234, stop_bias: float | None = Non
     if stop_bias is not None and "classifiers.proj.0.bias" in out:
         out["classifiers.proj.0.bias"][cfg.audio_tokens] = stop_bias
     return out
+
+
+LORA_TARGETS = ("self_attn.q_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj")
+
+
+def lora_state_dict_spec(cfg: Model, rank: int) -> "OrderedDict[str, tuple]":
+    """{name: shape} of the LoRA tensors the reference's ``apply_lora`` adds under the llama policy
+    (vall_e/config.py:519-530: self_attn and mlp linears, k_proj excluded; vall_e/models/lora.py:43-44:
+    lora_B (out, rank) then lora_A (rank, in))."""
+    base = state_dict_spec(cfg)
+    spec = OrderedDict()
+    for l in range(cfg.layers):
+        for t in LORA_TARGETS:
+            out_f, in_f = base[f"model.layers.{l}.{t}.weight"]
+            spec[f"model.layers.{l}.{t}.lora_B"] = (out_f, rank)
+            spec[f"model.layers.{l}.{t}.lora_A"] = (rank, in_f)
+    return spec
+
+
+def synth_lora_state_dict(cfg: Model, rank: int, seed: int = 4321, std: float = 0.05) -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic LoRA tensors for parity tests (a freshly initialised lora_B is zero, which would test nothing)."""
+    out = OrderedDict()
+    for idx, (name, shape) in enumerate(lora_state_dict_spec(cfg, rank).items()):
+        g = torch.Generator(device="cpu").manual_seed(seed + idx)
+        out[name] = std * torch.randn(shape, generator=g, dtype=torch.float32)
+    return out
