@@ -35,6 +35,20 @@ __global__ __launch_bounds__(256) void stream_kernel(const uint4* __restrict__ p
     if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) out[blockIdx.x] = acc;
 }
 
+// cache warmer: block (r, which) reads the first `bytes` of region r of the K (which = 0) or V cache with plain loads
+__global__ __launch_bounds__(256) void kv_prefetch_kernel(const uint4* __restrict__ k, const uint4* __restrict__ v, size_t region16, int n16, uint4* out) {
+    const uint4* base = (blockIdx.y ? v : k) + (size_t)blockIdx.x * region16;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (int i = threadIdx.x; i < n16; i += 256 * 4) {
+        uint4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = (i + j * 256 < n16) ? base[i + j * 256] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc.x ^= t[j].x; acc.y ^= t[j].y; acc.z ^= t[j].z; acc.w ^= t[j].w; }
+    }
+    if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) out[blockIdx.x] = acc;
+}
+
 // pseudo-random bf16 in (-2, 2) with random mantissas: realistic bit toggling (memset patterns run faster)
 __global__ void fill_rand(uint16_t* p, size_t n, uint32_t seed) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -183,6 +197,25 @@ int main(int argc, char** argv) {
     const double mb_layer = mb_qkv + mb_o + mb_gu + mb_dn + mb_att;
     if (timeit("WAVE LAYER (5 kernels)", mb_layer, false, wlayer)) return 1;
     if (timeit("WAVE LAYER (5 kernels)", mb_layer, true, wlayer)) return 1;
+    if (getenv("MICRO_PREFETCH")) {
+        // side stream warms the Infinity Cache with the NEXT layer's K/V rows while this layer runs; paced by one event per
+        // layer recorded on the main stream (mode 1: behind the QKV launch, 2: behind the attention launch, 3: events only,
+        // no prefetch kernel -- the price of the pacing alone)
+        const int mode = atoi(getenv("MICRO_PREFETCH"));
+        hipStream_t s2; CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        std::vector<hipEvent_t> ev(L); for (auto& evl : ev) CK(hipEventCreateWithFlags(&evl, hipEventDisableTiming));
+        hipEvent_t join; CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+        const size_t region16 = (size_t)CT * 128 / 16; const int n16 = (ctx + 1) * 128 / 16;
+        auto pace = [&](int l) {
+            (void)hipEventRecord(ev[l], s); (void)hipStreamWaitEvent(s2, ev[l], 0);
+            const int n = (l + 1) % L;
+            if (mode != 3) kv_prefetch_kernel<<<dim3(B * H, 2), 256, 0, s2>>>((const uint4*)kc[n], (const uint4*)vc[n], region16, n16, sink);
+            if (l == L - 1) { (void)hipEventRecord(join, s2); (void)hipStreamWaitEvent(s, join, 0); }
+        };
+        auto player = [&](int l) { int rc = w_qkv(l); if (mode != 2) pace(l); rc |= w_attn(l); if (mode == 2) pace(l); rc |= w_o(l); rc |= w_gu(l); rc |= w_dn(l); return rc; };
+        if (timeit("WAVE LAYER + next-layer KV prefetch", mb_layer, false, player)) return 1;
+        if (timeit("WAVE LAYER + next-layer KV prefetch", mb_layer, true, player)) return 1;
+    }
     printf("last error: %s\n", valle_last_error());
     return 0;
 }
