@@ -822,6 +822,37 @@ def scen_tiny_lora():
     print("  [tiny_lora] use_lora=False == no LoRA; adapted codes differ from plain")
 
 
+def scen_qnt_kat():
+    """Known answers of the code helpers in vall_e/emb/qnt.py (trim, repeat_extend_audio, get_silence,
+    pad_codes_with_silence, post_process, concat_audio) + an AR run with prefix_silence (models/ar_nar.py:730-732)."""
+    rh.load_reference()
+    from vall_e.emb import qnt as rq
+    g = torch.Generator().manual_seed(5)
+    clip = torch.randint(0, 1024, (37, 8), generator=g).to(torch.int16)
+    d = {"clip": clip}
+    targets = [1, 5, 36, 37, 38, 50, 0, -1, -5, -37, -40]
+    d["trim_targets"] = np.array(targets)
+    for t in targets:
+        d[f"trim_{t}"] = rq.trim(clip, t)
+        d[f"trimT_{t}"] = rq.trim(clip.t().contiguous(), t)              # (codebook, frame) orientation
+    ext = [1, 10, 37, 38, 74, 75, 200]
+    d["extend_targets"] = np.array(ext)
+    for t in ext:
+        d[f"extend_{t}"] = rq.repeat_extend_audio(clip, t)
+    secs = [0.0, 0.01, 0.1, 0.5, 1.0]
+    d["silence_seconds"] = np.array(secs)
+    for i, s_ in enumerate(secs):
+        d[f"silence_{i}"] = rq.get_silence(s_)
+    for size in (1, 2):
+        d[f"pad_{size}"] = rq.pad_codes_with_silence(clip, size)
+    d["post3"] = rq.post_process(clip.t()[None].contiguous())
+    d["post2"] = rq.post_process(clip)
+    d["concat"] = rq.concat_audio(clip[:3], None, clip[10:12])
+    save("qnt_kat", **d)
+    mk = lambda s: synth_batch(s, 2, n_phn=10, n_prom=16, ragged=True)
+    ar_nar_scenario("tiny_prefix_silence", "tiny", mk, 91, steps=10, ar_kw=dict(prefix_silence=0.1))
+
+
 def scen_full_b3():
     mk = lambda s: synth_batch(s, 3, n_phn=30, n_prom=60, ragged=True)
     ar_nar_scenario("full_b3", "full", mk, 61, steps=12)
@@ -873,6 +904,7 @@ SCENARIOS = {
     "tiny_tone": scen_tiny_tone,
     "tiny_unified_positions": scen_tiny_unified_positions,
     "tiny_lora": scen_tiny_lora,
+    "qnt_kat": scen_qnt_kat,
     "full_b1": scen_full_b1,
     "long": scen_long,
     "full_b3": scen_full_b3,

@@ -546,6 +546,7 @@ class Oracle:
         cfg_rescale = kw.pop("cfg_rescale", 0.7)
         input_prompt_prefix = kw.pop("input_prompt_prefix", False)
         refine_on_stop = kw.pop("refine_on_stop", False)
+        prefix_silence = kw.pop("prefix_silence", 0.0)
         B = len(phns)
         self.use_lora = kw.pop("use_lora", None)
         self.set_lora_level(0)                                           # ar_nar.py:619-620
@@ -555,6 +556,9 @@ class Oracle:
             start = [int(p.shape[0]) for p in proms]                         # open the response, the prompt segment is empty
             seqs = [p[:, 0].long() for p in proms]
             proms = [torch.zeros(0, dtype=torch.int64) for _ in proms]
+        elif prefix_silence > 0:                                             # ar_nar.py:730-732 with emb/qnt.py:586-593: floor(s * 75)
+            n_sil = math.floor(prefix_silence * 75)                          # frames of EnCodec silence, level 0 = code 62, kept
+            seqs = [torch.full((n_sil,), 62, dtype=torch.int64) for _ in range(B)]   # in the result (start_slice stays 0)
         if prefix_context is not None:
             prefix_text, prefix_resps, prefix_lens = prefix_context
             phns = [torch.cat([p[:-1].long(), t[1:].long()]) for p, t in zip(prefix_text, phns)]

@@ -297,6 +297,11 @@ def test_tiny_cfg(gpu_device):
     _ar_nar("tiny", "tiny_cfg")
 
 
+def test_tiny_prefix_silence(gpu_device):
+    """prefix_silence=0.1 (reference models/ar_nar.py:730-732, emb/qnt.py:586-593): AR + NAR codes == the reference's."""
+    _ar_nar("tiny", "tiny_prefix_silence")
+
+
 def test_tiny_lora_switched_per_level(gpu_device):
     """Per-level LoRA (reference models/lora.py:183-191 through ar_nar.py:539-540, :619-620), goldens made by the reference
     with apply_lora + synthetic lora_A / lora_B: rvq_levels [0, 2], every level, and the use_lora=False override."""

@@ -147,8 +147,7 @@ def test_unsupported_options_fail_loudly():
     m.sample_params(mirostat_tau=3.0, mirostat_eta=0.1)                  # accepted and without effect, as in the reference
     with pytest.raises(NotImplementedError):                            # (ar_nar.py:702-704 vs :804-808); an explicit state list is not
         m.sample_params(mirostat=[{"n": 1024, "tau": 3.0, "eta": 0.1}])
-    with pytest.raises(NotImplementedError):
-        m.sample_params(prefix_silence=0.5)
+    m.sample_params(prefix_silence=0.5)                                  # a forward_ar option (built); the sampler ignores it
     sp = m.sample_params(temperature=1.0, min_temperature=0.5, dry_multiplier=0.8, dry_allowed_length=1)
     assert (sp.temperature64, sp.min_temperature64, sp.dry_multiplier, sp.dry_allowed_length) == (1.0, 0.5, 0.8, 1)
     sp = m.sample_params(temperature=0.7, min_temperature=0.7004)       # closer than 0.001: plain temperature (base.py:1389)
@@ -359,3 +358,27 @@ def test_hf_token_ranges_and_round_trip():
             assert torch.equal(back[k], v), k
     from vall_e_amd.models import get_model
     get_model(cfg).load_state_dict(back, strict=True)
+
+
+def test_qnt_code_helpers_known_answers():
+    """vall_e_amd.emb.qnt against outputs of the reference's vall_e/emb/qnt.py (golden qnt_kat, oracle/gen_golden.py)."""
+    from conftest import load_golden
+    from vall_e_amd.emb import qnt
+    z = load_golden("qnt_kat")
+    clip = torch.from_numpy(z["clip"])
+    for t in z["trim_targets"].tolist():
+        np.testing.assert_array_equal(qnt.trim(clip, t).numpy(), z[f"trim_{t}"], err_msg=f"trim {t}")
+        np.testing.assert_array_equal(qnt.trim(clip.t().contiguous(), t).numpy(), z[f"trimT_{t}"], err_msg=f"trim^T {t}")
+    for t in z["extend_targets"].tolist():
+        np.testing.assert_array_equal(qnt.repeat_extend_audio(clip, t).numpy(), z[f"extend_{t}"], err_msg=f"extend {t}")
+    for i, s in enumerate(z["silence_seconds"].tolist()):
+        got = qnt.get_silence(s)
+        assert got.dtype == torch.int16
+        np.testing.assert_array_equal(got.numpy().reshape(z[f"silence_{i}"].shape), z[f"silence_{i}"])
+    for size in (1, 2):
+        np.testing.assert_array_equal(qnt.pad_codes_with_silence(clip, size).numpy(), z[f"pad_{size}"])
+    np.testing.assert_array_equal(qnt.post_process(clip.t()[None].contiguous()).numpy(), z["post3"])
+    np.testing.assert_array_equal(qnt.post_process(clip).numpy(), z["post2"])
+    np.testing.assert_array_equal(qnt.concat_audio(clip[:3], None, clip[10:12]).numpy(), z["concat"])
+    with pytest.raises(NotImplementedError):
+        qnt.decode(clip)

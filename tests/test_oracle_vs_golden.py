@@ -172,6 +172,13 @@ def test_tiny_cfg():
     _ar_nar("tiny", "tiny_cfg")
 
 
+def test_tiny_prefix_silence():
+    """ar_nar.py:730-732: floor(0.1 s * 75) = 7 frames of quantised silence (level-0 code 62) open the response and stay in it."""
+    z = load_golden("tiny_prefix_silence")
+    assert (z["ar_codes_0"][:7] == 62).all() and len(z["ar_codes_0"]) == 7 + int(z["steps"])
+    _ar_nar("tiny", "tiny_prefix_silence")
+
+
 def test_tiny_lora_switched_per_level():
     """models/lora.py:183-191 through ar_nar.py:539-540, :619-620: rvq_levels [0, 2] adapts the AR pass and NAR level 2 only;
     [] adapts every level; use_lora=False gives the plain model back."""

@@ -173,6 +173,15 @@ class TTS:
         ids = self.tokenizer.encode(text)
         return torch.tensor(ids, dtype=torch.uint8 if len(self.tokenizer.get_vocab()) < 256 else torch.int16)   # inference.py:284
 
+    def encode_audio(self, paths, trim_length=0.0):
+        """inference.py:139-169: a code tensor is returned as it is (``trim_length`` applies only to clips the
+        reference encodes from files, through ``repeat_extend_audio`` -- vall_e_amd.emb.qnt has it for callers that
+        hold codes); audio files need the codec networks, which are not built."""
+        if isinstance(paths, torch.Tensor):
+            return paths
+        raise NotImplementedError("encode_audio(path): waveform -> codes needs the codec (EnCodec / Vocos), not built; "
+                                  "pass the prompt as a (frames, 8) code tensor")
+
     def encode_lang(self, language):
         """inference.py:131-137."""
         return torch.tensor([self.LANG_SYMMAP.get(language, 0)], dtype=torch.uint8)
@@ -198,7 +207,8 @@ class TTS:
         seed = sampling_kwargs.pop("seed", None)              # None: a fresh one per call, as the reference does
         if seed is None:
             seed = derive_seed(None)
-        for k in ("input_prompt_length", "tqdm", "dtype", "amp", "voice_convert", "split_text_by"):
+        input_prompt_length = sampling_kwargs.pop("input_prompt_length", 0)
+        for k in ("tqdm", "dtype", "amp", "voice_convert", "split_text_by"):
             sampling_kwargs.pop(k, None)
         phonemize = sampling_kwargs.pop("phonemize", True)     # False: lines are raw-text ids, sent as text_list (inference.py:518-519)
         modality = self.modality(sampling_kwargs.pop("modality", "auto"))
@@ -207,7 +217,7 @@ class TTS:
         max_duration = sampling_kwargs.pop("max_duration", None)
         lines = text.split("\n") if isinstance(text, str) else list(text)
         lines = [l for l in lines if not isinstance(l, str) or l.strip()] or [""]
-        prom = references
+        prom = self.encode_audio(references, trim_length=input_prompt_length) if references is not None else None   # inference.py:486
         if task in ("ns", "sr"):                                                  # inference.py:489-493: the task token rides
             prom = [task, prom]                                                   # in front of the prompt; the model task stays tts
         lang = self.encode_lang(language) if isinstance(language, str) else language
@@ -256,7 +266,8 @@ class TTS:
         seed = sampling_kwargs.pop("seed", None)              # inference.py:315: set_seed per chunk; None = a fresh seed
         if seed is None:
             seed = derive_seed(None)
-        for k in ("input_prompt_length", "tqdm", "dtype", "amp"):
+        input_prompt_length = sampling_kwargs.pop("input_prompt_length", 0)
+        for k in ("tqdm", "dtype", "amp"):
             sampling_kwargs.pop(k, None)
         duration_padding = sampling_kwargs.pop("duration_padding", 1.05)
         n = len(texts)
@@ -264,6 +275,7 @@ class TTS:
         if languages and isinstance(languages[0], str):
             languages = [self.encode_lang(l) for l in languages]              # inference.py:286
         references = list(references) if references else [None] * n
+        references = [self.encode_audio(r, trim_length=input_prompt_length) if r is not None else None for r in references]   # inference.py:281
         languages = list(languages) if languages else [torch.tensor([0], dtype=torch.uint8)] * n
         lengths = [sort_key(t, r) for t, r in zip(texts, references)]
         mine = shard_utterances(lengths, world_size)[rank]

@@ -168,6 +168,7 @@ class AR_NAR(Base):
         prefix_context = kw.get("prefix_context", None)
         input_prompt_prefix = kw.pop("input_prompt_prefix", False)
         refine_on_stop = kw.pop("refine_on_stop", False)
+        prefix_silence = kw.pop("prefix_silence", 0.0)
         sp = self.sample_params(**kw)
         B = len(phns_list)
         dev = self.device
@@ -182,6 +183,9 @@ class AR_NAR(Base):
             start_slice = [int(_np(p).shape[0]) for p in proms_list]          # open the response; the prompt segment is empty
             prefix = [_np(p)[:, 0] for p in proms_list]
             proms_list = [torch.zeros(0, dtype=torch.int16) for _ in range(B)]
+        elif prefix_silence > 0:                                              # ar_nar.py:730-732: quantised silence opens the
+            from ..emb.qnt import get_silence                                 # response and stays in the result (no start_slice)
+            prefix = [_np(get_silence(prefix_silence))[:, 0].astype(np.int64) for _ in range(B)]
         if prefix_context is not None:                                        # ar_nar.py:736-742
             if any(isinstance(p, RawText) for p in phns_list):
                 raise TypeError("prefix_context splices phoneme lists; the reference fails the same way with text_list")

@@ -25,7 +25,7 @@ Sampled = namedtuple("Sampled", ["ids", "logits", "scores", "entropy"])         
 # mirostat_tau / mirostat_eta are accepted and change nothing, as in the reference: forward_ar builds the mirostat
 # state list (ar_nar.py:702-704) but its Base.sample call (:804-808) never passes ``mirostat=``, so basic sampling
 # runs (golden tiny_mirostat_tau).  Only a caller-made ``mirostat=[state, ...]`` kwarg reaches samplers.py:197-238.
-UNSUPPORTED_SAMPLERS = ("beam_width", "entropix_sampling", "prefix_silence", "layer_skip")
+UNSUPPORTED_SAMPLERS = ("beam_width", "entropix_sampling", "layer_skip")
 
 
 # data.py:670-688 (get_task_symmap): rows of tasks_emb
