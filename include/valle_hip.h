@@ -88,6 +88,15 @@ int valle_gemm(const void* A, const void* W, const void* bias, const void* resid
 int valle_gemm_qkv_rope(const void* A, const void* w_qkv, const float* rope, const int32_t* pos, void* qkv,
                         int M, int d, int K, void* stream);
 
+/* RMSNorm + nn.Linear in one launch for the dense bf16 passes (arch/llama.py:64-77 ahead of :307-309 and :492):
+ * C = epilogue((A . Wf^T) * rsqrt(mean(A[m]^2) + eps)), where Wf[n][k] = W[n][k] * norm_weight[k] (rounded to bf16
+ * once, on the host).  K is the whole row (the normalised width).  bf16 only, M >= 64, K % 64 == 0.
+ * epilogue: VALLE_EPI_STORE or VALLE_EPI_GEGLU; with rope + pos (both or neither; STORE only, N = 3 d_model, ldc = N)
+ * the q and k parts are rotated as in valle_gemm_qkv_rope.  Differs from valle_rmsnorm followed by valle_gemm only in
+ * where the roundings to bf16 fall (the normalised row is never rounded): same tolerance class as the decode kernels. */
+int valle_gemm_normed(const void* A, const void* Wf, void* C, int M, int N, int K, int ldc, int epilogue,
+                      float eps, const float* rope, const int32_t* pos, void* stream);
+
 /* RoPE on the q and k parts of packed qkv rows [M][3d] (in place, pair-interleaved head
  * layout, see w_qkv) using the fp32 table rope[pos][Dh/2][2] = (cos, sin)
  * (arch/llama.py:82-132, :48-61), then optionally copies the rotated k and v rows into a
@@ -221,8 +230,14 @@ typedef struct {
      * W[nt*16 + fr][ks*64 + half*32 + fq*8 .. +8], i.e. exactly the MFMA A fragment, so one wave-instruction
      * reads 1 KiB of contiguous memory and a wave's whole slice is contiguous.
      * pn_qkv / pn_gu: w_qkv / w_gu with the preceding RMSNorm weight multiplied in (W[n][k] * ln[k], rounded to
-     * bf16 once): the decode kernels apply 1/rms(x) to the accumulator instead of normalising x first. */
+     * bf16 once): the decode kernels apply 1/rms(x) to the accumulator instead of normalising x first.
+     * p_o / p_down are the streaming-order image of the NARROW-TILE row order of w_o / w_down, a [4 N][K/4] matrix
+     * W4 with W4[(n/4)*16 + q*4 + n%4][k] = W[n][q*(K/4) + k], q = 0..3 (vall-e_amd/models/base.py narrow_tile_rows):
+     * a 16-row tile then holds 4 output columns x the 4 quarters of K, and N/4 workgroups each own 4 columns. */
     const void *p_o, *p_down, *pn_qkv, *pn_gu;
+    /* bf16 dense-pass copies (may be NULL): w_qkv / w_gu row-major with the preceding RMSNorm weight multiplied in, as
+     * pn_qkv / pn_gu but not tiled; with them valle_forward_dense runs valle_gemm_normed and no separate RMSNorm. */
+    const void *f_qkv, *f_gu;
 } valle_layer_weights;
 
 typedef struct valle_model valle_model;

@@ -122,6 +122,49 @@ def test_gemm_qkv_rope_equals_gemm_then_rope(gpu_device):
     assert not torch.equal(a[:, :d].cpu(), (A.float() @ W[:d].float().T).bfloat16().cpu())       # the rotation did something
 
 
+@pytest.mark.parametrize("case", ["store", "geglu", "geglu_wide", "rope"])
+def test_gemm_normed_vs_fp64_and_unfused(gpu_device, case):
+    """valle_gemm_normed (RMSNorm folded into the weights, 1/rms applied to the accumulator) against the fp64
+    RMSNorm -> Linear of the reference semantics (arch/llama.py:64-77 + nn.Linear), and against the unfused
+    valle_rmsnorm + valle_gemm / valle_gemm_qkv_rope launches it replaces (same tolerance class: bf16 roundings move)."""
+    from vall_e_amd import _lib as L
+    lib = L.load()
+    bf = L.dtype_code(torch.bfloat16)
+    M, N, K = {"store": (333, 768, 256), "geglu": (200, 512, 256), "geglu_wide": (2500, 8192, 1024), "rope": (1100, 3072, 1024)}[case]
+    g = torch.Generator().manual_seed(N + K)
+    x = (torch.randn(M, K, generator=g) * (0.5 + 3 * torch.rand(M, 1, generator=g))).bfloat16()     # rows of different scale
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    ln = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16()
+    wf = (w.float() * ln.float()[None, :]).bfloat16()
+    xd, wd, lnd, wfd = (t.to(gpu_device) for t in (x, w, ln, wf))
+    epi = 2 if case.startswith("geglu") else 0
+    ldc = N // 2 if epi == 2 else N
+    got = torch.zeros((M, ldc), dtype=torch.bfloat16, device=gpu_device)
+    ref = torch.zeros_like(got)
+    h = torch.empty_like(xd)
+    rope = pos = None
+    if case == "rope":
+        inv = 1.0 / (10000.0 ** (torch.arange(0, 64, 2).float() / 64))
+        fr = torch.arange(512).float()[:, None] * inv[None, :]
+        rope = torch.stack((fr.cos(), fr.sin()), dim=-1).contiguous().to(gpu_device)
+        pos = torch.randint(0, 500, (M,), generator=g, dtype=torch.int32).to(gpu_device)
+    L.check(lib.valle_gemm_normed(L.ptr(xd), L.ptr(wfd), L.ptr(got), M, N, K, ldc, epi, 1e-6, L.ptr(rope), L.ptr(pos), L.stream_ptr()))
+    L.check(lib.valle_rmsnorm(L.ptr(xd), L.ptr(lnd), L.ptr(h), M, K, 1e-6, bf, L.stream_ptr()))
+    if case == "rope":
+        L.check(lib.valle_gemm_qkv_rope(L.ptr(h), L.ptr(wd), L.ptr(rope), L.ptr(pos), L.ptr(ref), M, N // 3, K, L.stream_ptr()))
+    else:
+        L.check(lib.valle_gemm(L.ptr(h), L.ptr(wd), None, None, L.ptr(ref), M, N, K, ldc, epi, bf, L.stream_ptr()))
+    got, ref = got.double().cpu(), ref.double().cpu()
+    assert ((got - ref).norm() / ref.norm()).item() < 1.5e-2
+    if case != "rope":
+        xn = x.double() * torch.rsqrt(x.double().pow(2).mean(-1, keepdim=True) + 1e-6) * ln.double()
+        acc = xn @ w.double().T
+        want = torch.nn.functional.gelu(acc[:, 0::2]) * acc[:, 1::2] if epi == 2 else acc
+        e_new = ((got - want).norm() / want.norm()).item()
+        e_old = ((ref - want).norm() / want.norm()).item()
+        assert e_new < 1e-2 and e_new < 1.5 * e_old + 1e-4, (e_new, e_old)     # no further from the truth than the unfused path
+
+
 def test_sampler_known_answers(gpu_device):
     """valle_sample / valle_cfg_combine against the reference's own sampler outputs (samplers_kat)."""
     m = hip_model("tiny")

@@ -382,3 +382,26 @@ def test_qnt_code_helpers_known_answers():
     np.testing.assert_array_equal(qnt.concat_audio(clip[:3], None, clip[10:12]).numpy(), z["concat"])
     with pytest.raises(NotImplementedError):
         qnt.decode(clip)
+
+
+def test_g2p_hook_language_coercion_and_pinyin_tones():
+    """emb/g2p.py:47-66, :118-128 restated; the espeak backend itself is a third-party package (absent): a registered
+    callable stands in and TTS.encode_text routes plain text through it (inference.py:129)."""
+    from vall_e_amd.emb import g2p
+    assert [g2p.coerce_language(l) for l in ("en", "fr", "zh", "zh-cn", "ja", "de", "en-gb")] == \
+        ["en-us", "fr-fr", "cmn-latn-pinyin", "cmn-latn-pinyin", "ja", "de", "en-gb"]
+    calls = []
+    def fake(text, language, punctuation=True, stress=True, strip=True):
+        calls.append((text, language))
+        return "ni3 hao3" if language == "cmn-latn-pinyin" else "həlˈoʊ"
+    g2p.set_backend(fake)
+    try:
+        assert g2p.encode("你好", language="zh") == "niˊ haoˊ"
+        assert g2p.encode("hello", language="en") == "həlˈoʊ" and calls[-1] == ("hello", "en-us")
+        with pytest.raises(ValueError):
+            g2p.encode("hello")
+    finally:
+        g2p.set_backend(None)
+    if not g2p.has_backend():
+        with pytest.raises(RuntimeError, match="no phonemizer backend"):
+            g2p.encode("hello", language="en")

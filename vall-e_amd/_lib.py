@@ -38,7 +38,7 @@ class Config(C.Structure):
 
 
 class LayerWeights(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("ln1", "w_qkv", "w_o", "ln2", "w_gu", "w_down", "p_o", "p_down", "pn_qkv", "pn_gu")]
+    _fields_ = [(n, C.c_void_p) for n in ("ln1", "w_qkv", "w_o", "ln2", "w_gu", "w_down", "p_o", "p_down", "pn_qkv", "pn_gu", "f_qkv", "f_gu")]
 
 
 class ARState(C.Structure):
@@ -59,6 +59,7 @@ SIGNATURES = {
     "valle_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
     "valle_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "valle_gemm_qkv_rope": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "valle_gemm_normed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "valle_rope_kv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                               c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "valle_attn_prefill": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -199,10 +199,30 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ X, c
 // XOR-swizzling the 16-B chunk index with (row & 7) on the GLOBAL source address and again on the read.
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int EPI>
+// NORM variants (RMSNorm folded into the weights, models/arch/llama.py:64-78 ahead of q/k/v and gate/up): the GEMM runs on
+// the un-normalised rows, every wave adds up the squares of the activation fragments it reads anyway (K = the whole row),
+// and the accumulators are scaled by 1/rms(row) before the epilogue rounds them.
+__device__ __forceinline__ float ssq8(const bf16x8& v, float acc) {
+    // (pairs by shufflevector: a bit_cast of the fragment to a 4-dword vector made the compiler read dword 0 four times)
+    const bf16x2 p0 = __builtin_shufflevector(v, v, 0, 1), p1 = __builtin_shufflevector(v, v, 2, 3);
+    const bf16x2 p2 = __builtin_shufflevector(v, v, 4, 5), p3 = __builtin_shufflevector(v, v, 6, 7);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(p0, p0, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(p1, p1, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(p2, p2, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(p3, p3, acc, false);
+    return acc;
+}
+// a lane's sum covers the k columns of its fq; the row's total is the sum over the 4 lanes fr + 16 fq
+__device__ __forceinline__ float row_rinv(float ss, int K, float eps) {
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    return 1.0f / sqrtf(ss * (1.0f / (float)K) + eps);
+}
+
+template <int EPI, bool NORM = false>
 __global__ __launch_bounds__(256) void gemm_glds_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W,
                                                              const void* __restrict__ bias, const bf16* resid,
-                                                             void* Cout, int M, int N, int K, int ldc) {
+                                                             void* Cout, int M, int N, int K, int ldc, float eps = 0.f) {
     __shared__ __attribute__((aligned(1024))) char lds[2][2][128 * 128];     // [buf][W | X][128 rows x 128 B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -259,6 +279,7 @@ __global__ __launch_bounds__(256) void gemm_glds_bf16_kernel(const bf16* __restr
         }
     }
     const int nt = K / 64;
+    [[maybe_unused]] float ssq[4] = {0.f, 0.f, 0.f, 0.f};
     stage(0, 0);
     for (int kt = 0; kt < nt; ++kt) {
         const int buf = kt & 1;
@@ -275,6 +296,10 @@ __global__ __launch_bounds__(256) void gemm_glds_bf16_kernel(const bf16* __restr
                 a[i] = *reinterpret_cast<const bf16x8*>(Ws + aoff[i][hf]);
                 b[i] = *reinterpret_cast<const bf16x8*>(Xs + boff[i][hf]);
             }
+            if constexpr (NORM) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ssq[j] = ssq8(b[j], ssq[j]);
+            }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -282,6 +307,14 @@ __global__ __launch_bounds__(256) void gemm_glds_bf16_kernel(const bf16* __restr
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
+        }
+    }
+    if constexpr (NORM) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float rinv = row_rinv(ssq[j], K, eps);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] *= rinv;
         }
     }
     if constexpr (EPI == GEMM_EPI_ROPE) {
@@ -382,10 +415,10 @@ __global__ __launch_bounds__(256) void gemm_glds_n64_bf16_kernel(const bf16* __r
 // buffer during the first three read slots of tile t -- that buffer's last fragment reads (tile t-1) were
 // waited for (lgkmcnt(0) before the barrier that ends a read slot) before tile t began -- and is waited for
 // (vmcnt(0)) in the 4th read slot, two barriers before its first read.
-template <int EPI>
+template <int EPI, bool NORM = false>
 __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W,
                                                               const void* __restrict__ bias, const bf16* resid,
-                                                              void* Cout, int M, int N, int K, int ldc) {
+                                                              void* Cout, int M, int N, int K, int ldc, float eps = 0.f) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * 65536];        // [buf][W 256 rows | X 256 rows] x 128 B
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -435,6 +468,13 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
             Bf[ct][1] = *reinterpret_cast<const bf16x8*>(L + bbase + (j * 32 + ct * 16) * 128 + sw1);
         }
     };
+    [[maybe_unused]] float ssq[4] = {0.f, 0.f, 0.f, 0.f};                 // per 16-row m tile j * 2 + ct
+    auto sq_b = [&](int j, bf16x8 (&Bf)[2][2]) {                           // (issued in an MFMA slot, behind the MFMAs)
+        if constexpr (NORM) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) ssq[j * 2 + ct] = ssq8(Bf[ct][1], ssq8(Bf[ct][0], ssq[j * 2 + ct]));
+        }
+    };
     auto quad = [&](int i, int j, bf16x8 (&Bf)[2][2]) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -464,11 +504,13 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
         if (st) stage_part(kt + 1, (kt + 1) & 1, 0, 2);
         PP_END_READ();
         quad(0, 0, B0);                                                   // M1
+        sq_b(0, B0);
         PP_END_MFMA();
         read_b(L, 1, B1);                                                 // R2
         if (st) stage_part(kt + 1, (kt + 1) & 1, 2, 5);
         PP_END_READ();
         quad(0, 1, B1);                                                   // M2
+        sq_b(1, B1);
         PP_END_MFMA();
         read_a(L, 1);                                                     // R3
         if (st) stage_part(kt + 1, (kt + 1) & 1, 5, 8);
@@ -483,6 +525,14 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
     if (grp == 0) __builtin_amdgcn_s_barrier();
 #undef PP_END_READ
 #undef PP_END_MFMA
+    if constexpr (NORM) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float rinv = row_rinv(ssq[j], K, eps);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i][j] *= rinv;
+        }
+    }
     gemm_epilogue<bf16, EPI, 8, 4>(acc, n0 + nh * 128, m0 + mq * 64, fr, fq, bias, resid, Cout, M, N, ldc);
 }
 
@@ -531,6 +581,30 @@ extern "C" int valle_gemm_qkv_rope(const void* A, const void* Wqkv, const float*
     const int N = 3 * d;
     dim3 grid(ceil_div(N, 128), ceil_div(M, 128));
     gemm_glds_bf16_kernel<GEMM_EPI_ROPE><<<grid, 256, 0, s>>>((const bf16*)A, (const bf16*)Wqkv, rope, (const bf16*)pos, qkv, M, N, K, N);
+    VALLE_LAUNCH_CHECK();
+    return VALLE_OK;
+}
+
+extern "C" int valle_gemm_normed(const void* A, const void* Wf, void* C, int M, int N, int K, int ldc, int epilogue,
+                                 float eps, const float* rope, const int32_t* pos, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    VALLE_REQUIRE(A && Wf && C, VALLE_E_ARG, "valle_gemm_normed: null pointer");
+    VALLE_REQUIRE(M >= 64 && N > 0 && K > 0 && K % 64 == 0, VALLE_E_UNSUPPORTED, "valle_gemm_normed: M=%d N=%d K=%d (M >= 64, K a multiple of 64)", M, N, K);
+    VALLE_REQUIRE(epilogue == VALLE_EPI_STORE || (epilogue == VALLE_EPI_GEGLU && !rope), VALLE_E_ARG, "valle_gemm_normed: epilogue %d", epilogue);
+    VALLE_REQUIRE(!rope == !pos, VALLE_E_ARG, "valle_gemm_normed: rope and pos come together");
+    VALLE_REQUIRE(epilogue != VALLE_EPI_GEGLU || (N % 4 == 0 && ldc % 2 == 0), VALLE_E_ARG, "valle_gemm_normed: EPI_GEGLU needs N %% 4 == 0");
+    VALLE_REQUIRE(ldc >= (epilogue == VALLE_EPI_GEGLU ? N / 2 : N), VALLE_E_ARG, "valle_gemm_normed: ldc %d too small", ldc);
+    VALLE_REQUIRE(!rope || (N % 192 == 0 && ldc == N), VALLE_E_ARG, "valle_gemm_normed: the RoPE epilogue takes N = 3 d_model, d_model a multiple of 64");
+    const bf16* X = (const bf16*)A; const bf16* W = (const bf16*)Wf;
+    if (epilogue == VALLE_EPI_GEGLU && N >= 4096 && M >= 1024) {
+        dim3 g256(ceil_div(N, 256), ceil_div(M, 256));
+        gemm_pp256_bf16_kernel<VALLE_EPI_GEGLU, true><<<g256, 512, 0, s>>>(X, W, nullptr, nullptr, C, M, N, K, ldc, eps);
+    } else {
+        dim3 grid(ceil_div(N, 128), ceil_div(M, 128));
+        if (epilogue == VALLE_EPI_GEGLU) gemm_glds_bf16_kernel<VALLE_EPI_GEGLU, true><<<grid, 256, 0, s>>>(X, W, nullptr, nullptr, C, M, N, K, ldc, eps);
+        else if (rope) gemm_glds_bf16_kernel<GEMM_EPI_ROPE, true><<<grid, 256, 0, s>>>(X, W, rope, (const bf16*)pos, C, M, N, K, ldc, eps);
+        else gemm_glds_bf16_kernel<VALLE_EPI_STORE, true><<<grid, 256, 0, s>>>(X, W, nullptr, nullptr, C, M, N, K, ldc, eps);
+    }
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
 }

@@ -154,20 +154,27 @@ extern "C" int valle_forward_dense(valle_model* m, const int32_t* emb_idx, const
     RUN(valle_embed_sum(m->emb, emb_idx, x, M, d, dt, s));
     for (int l = 0; l < c.n_layers; ++l) {
         const valle_layer_weights& w = m->layers[l];
-        RUN(valle_rmsnorm(x, w.ln1, h, M, d, c.rms_eps, dt, s));
+        // bf16 with folded weight copies: the two RMSNorms ride in the q/k/v and gate/up GEMMs (valle_gemm_normed)
+        const bool fold = dt == VALLE_BF16 && w.f_qkv && w.f_gu && M >= 64 && d % 64 == 0;
+        if (!fold) RUN(valle_rmsnorm(x, w.ln1, h, M, d, c.rms_eps, dt, s));
         void* kc = kcache ? (char*)kcache + (size_t)l * cache_layer_stride * es : nullptr;
         void* vc = vcache ? (char*)vcache + (size_t)l * cache_layer_stride * es : nullptr;
         if (dt == VALLE_BF16 && !kcache && Dh == 64 && d % 64 == 0 && M >= 64) {
             // passes without a KV cache (NAR levels, NAR-len steps): RoPE rides in the projection's epilogue
-            RUN(valle_gemm_qkv_rope(h, w.w_qkv, m->rope, pos, qkv, M, d, d, s));
+            if (fold) RUN(valle_gemm_normed(x, w.f_qkv, qkv, M, 3 * d, d, 3 * d, VALLE_EPI_STORE, c.rms_eps, m->rope, pos, s));
+            else RUN(valle_gemm_qkv_rope(h, w.w_qkv, m->rope, pos, qkv, M, d, d, s));
         } else {
-            RUN(valle_gemm(h, w.w_qkv, nullptr, nullptr, qkv, M, 3 * d, d, 3 * d, VALLE_EPI_STORE, dt, s));
+            if (fold) RUN(valle_gemm_normed(x, w.f_qkv, qkv, M, 3 * d, d, 3 * d, VALLE_EPI_STORE, c.rms_eps, nullptr, nullptr, s));
+            else RUN(valle_gemm(h, w.w_qkv, nullptr, nullptr, qkv, M, 3 * d, d, 3 * d, VALLE_EPI_STORE, dt, s));
             RUN(valle_rope_kv(qkv, pos, m->rope, cu_seqlens, B, M, H, Dh, kc, vc, cache_T, cache_slot, cache_pos0, dt, s));
         }
         RUN(valle_attn_prefill(qkv, h, cu_seqlens, B, M, max_T, H, Dh, causal, dt, s));
         RUN(valle_gemm(h, w.w_o, nullptr, x, x, M, d, d, d, VALLE_EPI_RESID, dt, s));
-        RUN(valle_rmsnorm(x, w.ln2, h, M, d, c.rms_eps, dt, s));
-        RUN(valle_gemm(h, w.w_gu, nullptr, nullptr, ff, M, 2 * f, d, f, VALLE_EPI_GEGLU, dt, s));
+        if (fold) RUN(valle_gemm_normed(x, w.f_gu, ff, M, 2 * f, d, f, VALLE_EPI_GEGLU, c.rms_eps, nullptr, nullptr, s));
+        else {
+            RUN(valle_rmsnorm(x, w.ln2, h, M, d, c.rms_eps, dt, s));
+            RUN(valle_gemm(h, w.w_gu, nullptr, nullptr, ff, M, 2 * f, d, f, VALLE_EPI_GEGLU, dt, s));
+        }
         RUN(valle_gemm(ff, w.w_down, nullptr, x, x, M, d, f, d, VALLE_EPI_RESID, dt, s));
     }
     if (n_out > 0) {

@@ -164,12 +164,16 @@ class TTS:
 
     def encode_text(self, text, language="auto", precheck=True, phonemize=True):
         """inference.py:111-129 for input that is already phonemes: a tensor passes through, an IPA string is
-        tokenised (``<bos> ... <eos>``).  Grapheme-to-phoneme conversion (espeak through ``phonemizer``,
-        emb/g2p.py) is not part of this package, so plain text must be phonemized by the caller."""
+        tokenised (``<bos> ... <eos>``).  With a grapheme-to-phoneme backend registered (``vall_e_amd.emb.g2p.set_backend``;
+        the reference's is espeak through ``phonemizer``, emb/g2p.py) plain text goes through it first, as :129 does;
+        without one -- or with ``language="ipa"`` -- the string is taken as phonemes."""
         if isinstance(text, torch.Tensor):
             return text
         if getattr(self, "tokenizer", None) is None:
             raise RuntimeError("no tokenizer loaded: call load_tokenizer(path to the reference's data/tokenizer.json)")
+        from .emb import g2p
+        if phonemize and language != "ipa" and g2p._backend is not None:        # inference.py:129: tokenize(g2p.encode(text, language))
+            text = g2p.encode(text, language=language)
         ids = self.tokenizer.encode(text)
         return torch.tensor(ids, dtype=torch.uint8 if len(self.tokenizer.get_vocab()) < 256 else torch.int16)   # inference.py:284
 

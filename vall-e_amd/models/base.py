@@ -248,7 +248,7 @@ class Base:
             b[f"down{l}"] = sd[p + "mlp.down_proj.weight"].to(dev, dt).contiguous()
             b[f"ln1_{l}"] = sd[p + "input_layernorm.weight"].to(dev, dt).contiguous()
             b[f"ln2_{l}"] = sd[p + "post_attention_layernorm.weight"].to(dev, dt).contiguous()
-            packed = [None] * 4
+            packed = [None] * 6
             if dt == torch.bfloat16 and d % 64 == 0:
                 for j, n in enumerate(("o", "down")):
                     b[f"p_{n}{l}"] = pack_stream_order(narrow_tile_rows(b[f"{n}{l}"], 4))
@@ -260,6 +260,8 @@ class Base:
                     folded = (host[n].float() * ln_host.float()[None, :]).to(dt)
                     b[f"pn_{n}{l}"] = pack_stream_order(folded).to(dev)
                     packed[2 + j] = b[f"pn_{n}{l}"].data_ptr()
+                    b[f"f_{n}{l}"] = folded.to(dev).contiguous()              # row-major, for the dense passes (valle_gemm_normed)
+                    packed[4 + j] = b[f"f_{n}{l}"].data_ptr()
             layers[l] = L.LayerWeights(b[f"ln1_{l}"].data_ptr(), b[f"qkv{l}"].data_ptr(), b[f"o{l}"].data_ptr(),
                                        b[f"ln2_{l}"].data_ptr(), b[f"gu{l}"].data_ptr(), b[f"down{l}"].data_ptr(), *packed)
         return layers
