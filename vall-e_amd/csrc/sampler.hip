@@ -410,6 +410,16 @@ __global__ __launch_bounds__(64) void sample_greedy_wave_kernel(SampleArgs a) {
     int n_prev = 0;
     if (a.prev_is_seq) n_prev = a.seq_len[item];
     else if (a.prev != nullptr) n_prev = a.prev_len[item];
+    // the append's state is requested now, beside the logits: read behind the argmax, each of these loads would be one
+    // more dependent round trip (~1 us) in front of the next step's embedding row
+    const bool append = a.seq != nullptr;                       // AR: one row per utterance
+    int st_stopped = 0, st_n = 0, st_ctx = 0, st_ctx2 = 0;
+    if (append) {
+        st_stopped = a.stopped[item];
+        st_n = a.seq_len[item];
+        if (a.ctx_len) st_ctx = a.ctx_len[item];
+        if (a.ctx_len2) st_ctx2 = a.ctx_len2[item];
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) mx = fmaxf(mx, x[j]);
@@ -447,32 +457,33 @@ __global__ __launch_bounds__(64) void sample_greedy_wave_kernel(SampleArgs a) {
     for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
     int tok = best;
     if (tok >= V || all_masked) tok = 0;                        // torch.argmax of an all -inf / nan row
-    if (lane == 0) {
-        a.ids[row] = tok;
-        if (a.scores) a.scores[row] = 1.0f / se;               // exp(x[tok] - mx) = 1; nan when the row is all -inf / nan
-        if (a.seq != nullptr && !(a.early_exit && a.stopped[item])) {   // fused AR append (models/ar_nar.py:837-842)
-            const int n = a.seq_len[item];
-            if (n < a.seq_cap) a.seq[(size_t)item * a.seq_cap + n] = tok;
-            a.seq_len[item] = n + 1;
-            if (a.ctx_len) {
-                const int ctx1 = a.ctx_len[item] + 1;
-                // early exit: a finished utterance's context is stored as ~ctx_len (negative) -- the decode kernels read
-                // ctx_len anyway and leave on a negative value, with no further flag to fetch
-                a.ctx_len[item] = (a.early_exit && tok == a.p.stop_token) ? ~ctx1 : ctx1;
-            }
-            if (a.ctx_len2) a.ctx_len2[item] = a.ctx_len2[item] + 1;     // second cache of the guidance loop
-            if (tok == a.p.stop_token) a.stopped[item] = 1;
-        }
-    }
-    if (a.nx_x != nullptr) {                                    // next step's fragment-order x and position
-        const bf16* src = a.nx_emb + (size_t)(a.nx_row0 + tok) * a.nx_d;
+    if (a.nx_x != nullptr) {                                    // next step's fragment-order x and position (its loads go
+        const bf16* src = a.nx_emb + (size_t)(a.nx_row0 + tok) * a.nx_d;        // out before the bookkeeping stores below)
+        const int npos = (a.nx_pos0 ? a.nx_pos0[item] : 0) + n_prev;
+        float rp = 0.f;
+        if (a.nx_rope) rp = a.nx_rope_tab[(size_t)npos * 64 + lane];
         for (int c = lane * 8; c < a.nx_d; c += 64 * 8) {
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c);
             *reinterpret_cast<bf16x8*>(a.nx_x + (size_t)(item >> 4) * 16 * a.nx_d + dec_frag_off<1>(item & 15, c, a.nx_d)) = v;
         }
-        const int npos = (a.nx_pos0 ? a.nx_pos0[item] : 0) + n_prev;
         if (lane == 0) a.nx_pos[item] = npos;
-        if (a.nx_rope) a.nx_rope[item * 64 + lane] = a.nx_rope_tab[(size_t)npos * 64 + lane];
+        if (a.nx_rope) a.nx_rope[item * 64 + lane] = rp;
+    }
+    if (lane == 0) {
+        a.ids[row] = tok;
+        if (a.scores) a.scores[row] = 1.0f / se;               // exp(x[tok] - mx) = 1; nan when the row is all -inf / nan
+        if (append && !(a.early_exit && st_stopped)) {         // fused AR append (models/ar_nar.py:837-842)
+            if (st_n < a.seq_cap) a.seq[(size_t)item * a.seq_cap + st_n] = tok;
+            a.seq_len[item] = st_n + 1;
+            if (a.ctx_len) {
+                const int ctx1 = st_ctx + 1;
+                // early exit: a finished utterance's context is stored as ~ctx_len (negative) -- the decode kernels read
+                // ctx_len anyway and leave on a negative value, with no further flag to fetch
+                a.ctx_len[item] = (a.early_exit && tok == a.p.stop_token) ? ~ctx1 : ctx1;
+            }
+            if (a.ctx_len2) a.ctx_len2[item] = st_ctx2 + 1;    // second cache of the guidance loop
+            if (tok == a.p.stop_token) a.stopped[item] = 1;
+        }
     }
 }
 
