@@ -1,5 +1,7 @@
 // Dev micro-benchmark (not part of the library): the dense-pass GEMM shapes of one NAR level
-// (B=16 x T=761 = 12,176 rows) through valle_gemm, bf16, random operands.
+// (B=16 x T=761 = 12,176 rows) as valle_forward_dense launches them in bf16: q/k/v (+ RoPE) and gate/up through
+// valle_gemm_normed (RMSNorm folded in), o_proj and down_proj through valle_gemm; random operands.
+// MICRO_GEMM_UNFUSED=1: the q/k/v and gate/up GEMMs without the folded norm (valle_gemm_qkv_rope / valle_gemm).
 #include "../vall-e_amd/csrc/common.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -27,14 +29,25 @@ int main(int argc, char** argv) {
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     double tot = 0;
+    float* rope; int32_t* pos;
+    CK(hipMalloc(&rope, 1024 * 64 * 4)); CK(hipMemset(rope, 0, 1024 * 64 * 4));
+    CK(hipMalloc(&pos, (size_t)M * 4)); CK(hipMemset(pos, 0, (size_t)M * 4));
+    const bool unfused = getenv("MICRO_GEMM_UNFUSED") != nullptr;
     for (auto& sh : shapes) {
         const int ldc = sh.epi == VALLE_EPI_GEGLU ? sh.N / 2 : sh.N;
+        auto run = [&]() -> int {
+            if (sh.epi == VALLE_EPI_STORE)
+                return unfused ? valle_gemm_qkv_rope(A, W, rope, pos, C, M, sh.N / 3, sh.K, s)
+                               : valle_gemm_normed(A, W, C, M, sh.N, sh.K, ldc, VALLE_EPI_STORE, 1e-6f, rope, pos, s);
+            if (sh.epi == VALLE_EPI_GEGLU && !unfused) return valle_gemm_normed(A, W, C, M, sh.N, sh.K, ldc, VALLE_EPI_GEGLU, 1e-6f, nullptr, nullptr, s);
+            return valle_gemm(A, W, nullptr, R, C, M, sh.N, sh.K, ldc, sh.epi, VALLE_BF16, s);
+        };
         for (int i = 0; i < 3; ++i)
-            if (valle_gemm(A, W, nullptr, R, C, M, sh.N, sh.K, ldc, sh.epi, VALLE_BF16, s)) { printf("error: %s\n", valle_last_error()); return 1; }
+            if (run()) { printf("error: %s\n", valle_last_error()); return 1; }
         CK(hipStreamSynchronize(s));
         const int reps = 20;
         CK(hipEventRecord(e0, s));
-        for (int i = 0; i < reps; ++i) valle_gemm(A, W, nullptr, R, C, M, sh.N, sh.K, ldc, sh.epi, VALLE_BF16, s);
+        for (int i = 0; i < reps; ++i) run();
         CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / reps, tf = 2.0 * M * sh.N * sh.K / us * 1e-6;
