@@ -206,7 +206,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(const bf16* _
         const int col = h * 64 + threadIdx.x;
         const size_t off = a.out_frag ? (size_t)(b >> 4) * 16 * H * 64 + dec_frag_off<DEC_S_O>(b & 15, col, H * 64)
                                       : (size_t)b * H * 64 + col;
-        pOut[off] = (bf16)(num / den);
+        pOut[off] = (bf16)(num / den);   // (as a non-temporal store: 9.33 vs 8.78 us)
 #ifdef VALLE_STAMPS
         if (a.stamps) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -26,6 +26,11 @@
 
 // weights are read once per step by one CU: non-temporal loads keep them from displacing the activations in the
 // caches (measured on the layer chain, tools/micro_dec: 28.4 -> 28.1 us per layer)
+#ifdef VALLE_NT_ST      // dev: outputs by non-temporal stores (measured: see profiles/README.md)
+#define STORE_OUT(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define STORE_OUT(p, v) (*(p) = (v))
+#endif
 #ifdef VALLE_NO_NT_W
 #define LOAD_W(p) (*(p))
 #else
@@ -185,12 +190,12 @@ __global__ __launch_bounds__(64 * NWK) void dec_wave_kernel(const bf16* __restri
             bf16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = (bf16)((float)rs[r] + (float)(bf16)sum[r]);
-            *reinterpret_cast<bf16x4*>((bf16*)pOut + (size_t)mt * 16 * N + dec_frag_off<1>(fr, n, N)) = o;
+            STORE_OUT(reinterpret_cast<bf16x4*>((bf16*)pOut + (size_t)mt * 16 * N + dec_frag_off<1>(fr, n, N)), o);
         } else if constexpr (EPI == VALLE_EPI_GEGLU) {
             bf16x2 o;
             o[0] = (bf16)((float)(bf16)gelu_erf((float)(bf16)sum[0]) * (float)(bf16)sum[1]);
             o[1] = (bf16)((float)(bf16)gelu_erf((float)(bf16)sum[2]) * (float)(bf16)sum[3]);
-            *reinterpret_cast<bf16x2*>((bf16*)pOut + (size_t)mt * 16 * (N >> 1) + dec_frag_off<DEC_S_DOWN>(fr, n >> 1, N >> 1)) = o;
+            STORE_OUT(reinterpret_cast<bf16x2*>((bf16*)pOut + (size_t)mt * 16 * (N >> 1) + dec_frag_off<DEC_S_DOWN>(fr, n >> 1, N >> 1)), o);
         } else if constexpr (EPI == VALLE_EPI_F32OUT) {
             float* o = (float*)pOut + (size_t)m * a.ldo + n;
 #pragma unroll
@@ -212,10 +217,10 @@ __global__ __launch_bounds__(64 * NWK) void dec_wave_kernel(const bf16* __restri
                 }
             }
             if (which == 0) {
-                *reinterpret_cast<bf16x4*>((bf16*)pOut + (size_t)m * a.ldo + n) = o;
+                STORE_OUT(reinterpret_cast<bf16x4*>((bf16*)pOut + (size_t)m * a.ldo + n), o);
             } else if (cpos >= 0) {                    // a negative ctx_len marks a finished utterance (early exit): no append
                 bf16* cp = (which == 1 ? a.kc : a.vc) + (((size_t)csl * a.H + h) * a.cache_T + cpos) * 64 + e;
-                *reinterpret_cast<bf16x4*>(cp) = o;
+                STORE_OUT(reinterpret_cast<bf16x4*>(cp), o);
             }
         }
     }
