@@ -195,6 +195,15 @@ int valle_sample_append(const float* logits, int ld, int vocab, int B, const val
                         int32_t* seq, int seq_cap, int32_t* seq_len, int32_t* ctx_len, int32_t* ctx_len2,
                         int32_t* stopped, int32_t* ids, float* scores, void* stream);
 
+/* Beam search step (models/base.py:1412-1415 with samplers.py:148-160; loop at models/ar_nar.py:821-842): the sampler chain
+ * of valle_sample in AR mode (prev = seq[r][:seq_len[r]]) on logits [rows][ld], then the beam_width best (row, token) pairs
+ * of the flattened processed logits, best first.  Out: ids[i] = token of candidate i, scores[i] = its processed logit (may be
+ * NULL), forced [beam_width][ld] = -inf except 0 at ids[i] -- a greedy valle_sample_append on it appends candidate i to
+ * sequence i, as the reference does whichever row the candidate came from.  proc [rows][ld]: scratch (processed logits). */
+int valle_beam_pick(const float* logits, int ld, int vocab, int rows, int beam_width,
+                    const valle_sample_params* params, const int32_t* seq, int seq_cap, const int32_t* seq_len,
+                    float* proc, float* forced, int32_t* ids, float* scores, void* stream);
+
 /* Integer table patch: dst[rows[i]][c0 + c] = src[i][s0 + c] + add for i < n, c < ncols (rows == NULL: row i; dst int32 or,
  * dst_is_i64 != 0, int64).  The host plans the gather tables of a dense pass before the codes exist (Base.inputs,
  * models/base.py:560-735); the device fills in the codes as they are sampled (the torch.cat / tensor rebuilds of

@@ -853,6 +853,39 @@ def scen_qnt_kat():
     ar_nar_scenario("tiny_prefix_silence", "tiny", mk, 91, steps=10, ar_kw=dict(prefix_silence=0.1))
 
 
+def scen_tiny_beam():
+    """Beam search as the version-5 reference runs it (models/ar_nar.py:821-842, :865-867; base.py:1412-1415): one utterance
+    WITHOUT a language list (the beam expansion does not expand it, so any call with one raises IndexError at the second
+    step -- the reason TTS.inference cannot reach this path), beam_width 3, temperature 1.0.  Every step's top-(W+1)
+    candidate values are recorded: the test needs their order to be safe against the logit error."""
+    ref = rh.load_reference()
+    import vall_e.models.base as rb
+    model, mcfg = get_ref_model("tiny")
+    for s_ in range(101, 117):
+        phns, proms, _ = synth_batch(s_, 1, n_phn=10, n_prom=16)
+        gaps = []
+        orig = rb.top_k_logits_list
+        def wrapped(logits_list, k):
+            flat = torch.cat(logits_list).flatten().float()
+            v = torch.topk(flat, k + 1).values
+            gaps.append(float((v[:-1] - v[1:]).min()))
+            return orig(logits_list, k)
+        rb.top_k_logits_list = wrapped
+        try:
+            with torch.inference_mode():
+                out = model(task_list=["tts"], phns_list=[p.clone() for p in phns], proms_list=[p.clone() for p in proms],
+                            lang_list=None, disable_tqdm=True, max_duration=10, temperature=1.0, beam_width=3)
+        finally:
+            rb.top_k_logits_list = orig
+        print(f"  [tiny_beam] seed {s_}: codes {out[0].tolist()} min candidate gap {min(gaps):.3e}")
+        if min(gaps) > 1e-3:
+            d = {"phn_0": phns[0], "prom_0": proms[0], "batch": np.int64(1), "steps": np.int64(10), "beam_width": np.int64(3),
+                 "ar_codes_0": out[0], "candidate_gaps": np.array(gaps), "input_seed": np.int64(s_)}
+            save("tiny_beam", **d)
+            return
+    raise RuntimeError("tiny_beam: no seed with a safe candidate order")
+
+
 def scen_full_b3():
     mk = lambda s: synth_batch(s, 3, n_phn=30, n_prom=60, ragged=True)
     ar_nar_scenario("full_b3", "full", mk, 61, steps=12)
@@ -905,6 +938,7 @@ SCENARIOS = {
     "tiny_unified_positions": scen_tiny_unified_positions,
     "tiny_lora": scen_tiny_lora,
     "qnt_kat": scen_qnt_kat,
+    "tiny_beam": scen_tiny_beam,
     "full_b1": scen_full_b1,
     "long": scen_long,
     "full_b3": scen_full_b3,

@@ -244,8 +244,8 @@ def cfg_combine(pos_logits, null_logits, strength, lens, rescale=0.0):
 def sample(logits, prev_list=None, quant_levels=None, *, causal_size=1, stop_token=1024, generator=None,
            temperature=1.0, min_temperature=-1.0, top_k=-100, top_p=1.0, min_p=0.0,
            repetition_penalty=1.0, repetition_penalty_decay=0.0, length_penalty=0.0, top_no=1.0,
-           dry_multiplier=0.0, dry_base=1.75, dry_allowed_length=2, **_unused):
-    """Base.sample (base.py:1280-1430), basic branch (no beam / mirostat / entropix).
+           dry_multiplier=0.0, dry_base=1.75, dry_allowed_length=2, beam_width=0, **_unused):
+    """Base.sample (base.py:1280-1430), basic branch and beam branch (no mirostat / entropix).
     Returns (ids, processed_logits, scores)."""
     if min_temperature < 0:
         min_temperature = temperature
@@ -272,6 +272,12 @@ def sample(logits, prev_list=None, quant_levels=None, *, causal_size=1, stop_tok
         logits = [top_n_sigma(l) for l in logits]
     if dry_multiplier > 0.0 and prev_list is not None:                       # :1399-1400
         logits = [dry_sampling(l, p, dry_multiplier, dry_base, dry_allowed_length) for l, p in zip(logits, prev_list)]
+    if beam_width > 1:                                                       # base.py:1412-1415 with samplers.py:148-160: the
+        flat = torch.cat(logits)                                             # beam_width best (row, token) pairs of ALL rows,
+        V = flat.shape[-1]                                                   # best first; candidate i goes to sequence i
+        idx = torch.topk(flat.flatten(), beam_width).indices.tolist()
+        ids = [torch.tensor([i % V]) for i in idx]
+        return ids, logits, [flat[i // V, i % V] for i in idx]
     if temperature <= 0.0:
         ids = [l.argmax(dim=-1) for l in logits]
     else:
@@ -547,6 +553,7 @@ class Oracle:
         input_prompt_prefix = kw.pop("input_prompt_prefix", False)
         refine_on_stop = kw.pop("refine_on_stop", False)
         prefix_silence = kw.pop("prefix_silence", 0.0)
+        beam_width = kw.get("beam_width", 0)
         B = len(phns)
         self.use_lora = kw.pop("use_lora", None)
         self.set_lora_level(0)                                           # ar_nar.py:619-620
@@ -581,12 +588,20 @@ class Oracle:
                 last_logits.append(torch.stack([l[-1].float() for l in logits]))
             ids, _, _ = sample(logits, prev_list=seqs, causal_size=self.causal_size, stop_token=self.stop_token,
                                generator=generator, **kw)
-            for i in range(B):
+            if beam_width > 0 and B == 1:                                    # ar_nar.py:821-832: first step, the batch becomes the
+                B = beam_width                                               # beam (the language list is NOT expanded there: with
+                if langs is not None and B > 1:                              # one the reference dies of an IndexError next step)
+                    raise IndexError("list index out of range")
+                phns, proms, seqs, start = phns * B, proms * B, seqs * B, start * B
+                null_phn, stopped = null_phn * B, [False] * B
+            for i in range(len(ids)):
                 if self.stop_token in ids[i]:
                     stopped[i] = True
                 seqs[i] = torch.cat([seqs[i], ids[i].long()])
             if all(stopped):
                 break
+        if beam_width:                                                       # ar_nar.py:865-867: "always candidate 0"
+            seqs = seqs[:1]
         out = []
         for i, s in enumerate(seqs):
             hit = (s == self.stop_token).nonzero()

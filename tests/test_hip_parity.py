@@ -340,6 +340,20 @@ def test_tiny_cfg(gpu_device):
     _ar_nar("tiny", "tiny_cfg")
 
 
+def test_tiny_beam_search(gpu_device):
+    """beam_width=3 on one utterance without a language list (the only form the version-5 reference can run,
+    models/ar_nar.py:821-842, :865-867; models/base.py:1412-1415): codes == the reference's."""
+    z = load_golden("tiny_beam")
+    m = hip_model("tiny")
+    phns, proms = [torch.from_numpy(z["phn_0"])], [torch.from_numpy(z["prom_0"])]
+    out = m(task_list=["tts"], phns_list=phns, proms_list=proms, lang_list=None, max_duration=int(z["steps"]),
+            temperature=1.0, beam_width=int(z["beam_width"]))
+    assert len(out) == 1
+    np.testing.assert_array_equal(out[0].cpu().numpy(), z["ar_codes_0"])
+    with pytest.raises(IndexError):
+        m(task_list=["tts"], phns_list=phns, proms_list=proms, lang_list=[torch.tensor([0])], max_duration=3, beam_width=3)
+
+
 def test_tiny_prefix_silence(gpu_device):
     """prefix_silence=0.1 (reference models/ar_nar.py:730-732, emb/qnt.py:586-593): AR + NAR codes == the reference's."""
     _ar_nar("tiny", "tiny_prefix_silence")

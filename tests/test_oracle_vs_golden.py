@@ -172,6 +172,18 @@ def test_tiny_cfg():
     _ar_nar("tiny", "tiny_cfg")
 
 
+def test_tiny_beam_search():
+    """Beam search as the reference runs it (no language list; ar_nar.py:821-842, base.py:1412-1415)."""
+    z = load_golden("tiny_beam")
+    o = make_oracle("tiny")
+    phns, proms = [torch.from_numpy(z["phn_0"])], [torch.from_numpy(z["prom_0"])]
+    out = o.ar(phns, proms, None, max_duration=int(z["steps"]), temperature=1.0, beam_width=int(z["beam_width"]))
+    assert len(out) == 1
+    np.testing.assert_array_equal(out[0].numpy(), z["ar_codes_0"])
+    with pytest.raises(IndexError):                                   # with a language list the reference fails at step 2
+        o.ar(phns, proms, [torch.tensor([0])], max_duration=3, temperature=1.0, beam_width=3)
+
+
 def test_tiny_prefix_silence():
     """ar_nar.py:730-732: floor(0.1 s * 75) = 7 frames of quantised silence (level-0 code 62) open the response and stay in it."""
     z = load_golden("tiny_prefix_silence")

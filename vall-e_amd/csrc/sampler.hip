@@ -306,6 +306,11 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
             return (float)(a.p.dry_multiplier * pow(a.p.dry_base, (double)(length - allowed)));
         });
     }
+    if (a.proc_out != nullptr) {        // beam search picks across rows (valle_beam_pick): hand the processed row over
+        __syncthreads();
+        for (int v = tid; v < V; v += SAMP_THREADS) a.proc_out[(size_t)row * a.ld + v] = vals[v];
+        return;
+    }
     // ---- pick: argmax (lowest index on ties) or categorical
     float mx = -INFINITY;
     for (int v = tid; v < V; v += SAMP_THREADS) mx = fmaxf(mx, vals[v]);
@@ -496,7 +501,7 @@ static bool sample_is_plain_greedy(const SampleArgs& a) {
 }
 
 int valle_sample_launch(const SampleArgs& a, int rows, hipStream_t s) {
-    if (sample_is_plain_greedy(a)) {
+    if (a.proc_out == nullptr && sample_is_plain_greedy(a)) {
         if (a.vocab <= 64 * 17) sample_greedy_wave_kernel<17><<<rows, 64, 0, s>>>(a);
         else sample_greedy_wave_kernel<32><<<rows, 64, 0, s>>>(a);
     } else {
@@ -654,6 +659,57 @@ extern "C" int valle_sample_append(const float* logits, int ld, int vocab, int B
     a.seq = seq; a.seq_cap = seq_cap; a.seq_len = seq_len; a.ctx_len = ctx_len; a.ctx_len2 = ctx_len2; a.stopped = stopped;
     a.prev_is_seq = 1;
     return valle_sample_launch(a, B, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------- beam search (models/base.py:1412-1415)
+// top-W of the flattened [rows][vocab] processed logits (samplers.py:148-160), best first, ties to the lower flat index;
+// candidate i = (row, token) gives ids[i] = token, scores[i] = its logit, and forced[i][..] = -inf except 0 at the token,
+// so that a greedy valle_sample_append on `forced` appends token i to sequence i -- the reference's (naive) re-batching
+// hands candidate i to sequence i whichever row it came from (models/ar_nar.py:837-842).
+__global__ __launch_bounds__(256) void beam_pick_kernel(float* __restrict__ proc, int ld, int V, int rows, int W,
+                                                        float* __restrict__ forced, int32_t* __restrict__ ids,
+                                                        float* __restrict__ scores) {
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    const int tid = threadIdx.x;
+    for (int i = 0; i < W; ++i) {
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int t = tid; t < rows * V; t += 256) {
+            const float x = proc[(size_t)(t / V) * ld + (t % V)];
+            if (x > best || (x == best && t < bi)) { best = x; bi = t; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if ((tid & 63) == 0) { s_val[tid >> 6] = best; s_idx[tid >> 6] = bi; }
+        __syncthreads();
+        best = s_val[0]; bi = s_idx[0];
+        for (int w = 1; w < 4; ++w) if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bi)) { best = s_val[w]; bi = s_idx[w]; }
+        if (bi == 0x7fffffff) bi = 0;                       // a matrix of NaNs compares false everywhere
+        const int tok = bi % V;
+        if (tid == 0) { ids[i] = tok; if (scores) scores[i] = best; proc[(size_t)(bi / V) * ld + tok] = -INFINITY; }
+        for (int v = tid; v < V; v += 256) forced[(size_t)i * ld + v] = (v == tok) ? 0.f : -INFINITY;
+        __syncthreads();
+    }
+}
+
+extern "C" int valle_beam_pick(const float* logits, int ld, int vocab, int rows, int beam_width,
+                               const valle_sample_params* params, const int32_t* seq, int seq_cap, const int32_t* seq_len,
+                               float* proc, float* forced, int32_t* ids, float* scores, void* stream) {
+    VALLE_REQUIRE(logits && params && seq && seq_len && proc && forced && ids, VALLE_E_ARG, "valle_beam_pick: null pointer");
+    VALLE_REQUIRE(vocab > 1 && vocab <= SAMP_MAXV && ld >= vocab && rows >= 1 && beam_width >= 1 && beam_width <= rows * vocab,
+                  VALLE_E_ARG, "valle_beam_pick: vocab %d, ld %d, rows %d, beam_width %d", vocab, ld, rows, beam_width);
+    SampleArgs a{};
+    a.logits = logits; a.ld = ld; a.vocab = vocab; a.nar_mode = 0; a.p = *params;
+    a.ids = ids; a.seq = const_cast<int32_t*>(seq); a.seq_cap = seq_cap; a.seq_len = const_cast<int32_t*>(seq_len);
+    a.prev_is_seq = 1; a.proc_out = proc;
+    int rc = valle_sample_launch(a, rows, (hipStream_t)stream);
+    if (rc != VALLE_OK) return rc;
+    beam_pick_kernel<<<1, 256, 0, (hipStream_t)stream>>>(proc, ld, vocab, rows, beam_width, forced, ids, scores);
+    VALLE_LAUNCH_CHECK();
+    return VALLE_OK;
 }
 
 // ---------------------------------------------------------------------- integer bookkeeping of the NAR / NAR-len loops

@@ -169,6 +169,21 @@ class AR_NAR(Base):
         input_prompt_prefix = kw.pop("input_prompt_prefix", False)
         refine_on_stop = kw.pop("refine_on_stop", False)
         prefix_silence = kw.pop("prefix_silence", 0.0)
+        beam_width = int(kw.pop("beam_width", 0) or 0)
+        if beam_width == 1:
+            beam_width = 0          # base.py:1412 needs > 1; a beam of one is plain sampling (the scores it keeps are unused)
+        if beam_width > 1:
+            # ar_nar.py:821-832: the first step turns the one utterance into beam_width sequences -- text, prompt, sequence,
+            # task, but not the language list, which therefore cannot be given (IndexError at the second step in the reference)
+            if len(phns_list) != 1:
+                raise NotImplementedError("beam search starts from one utterance (ar_nar.py:825)")
+            if lang_list is not None:
+                raise IndexError("list index out of range (beam search does not expand lang_list, ar_nar.py:825-832)")
+            if cfg_strength > 0 or prefix_context is not None or input_prompt_prefix or refine_on_stop or return_logits \
+                    or any(isinstance(p, RawText) for p in phns_list):
+                raise NotImplementedError("beam search together with guidance / prefix_context / input_prompt_prefix / "
+                                          "refine_on_stop / return_logits / raw text")
+            phns_list, proms_list = list(phns_list) * beam_width, list(proms_list) * beam_width
         sp = self.sample_params(**kw)
         B = len(phns_list)
         dev = self.device
@@ -252,6 +267,29 @@ class AR_NAR(Base):
         stream = L.stream_ptr(dev)
         all_logits = []
 
+        if beam_width > 1:
+            # host-driven steps: the stack runs the newest token of every sequence, the device picks the beam_width best
+            # (row, token) pairs of all rows and appends candidate i to sequence i (valle_beam_pick + a forced greedy append)
+            proc = torch.empty((B, ld), dtype=torch.float32, device=dev)
+            forced = torch.empty((B, ld), dtype=torch.float32, device=dev)
+            last = torch.empty((B, ld), dtype=torch.float32, device=dev)
+            ids = torch.empty(B, dtype=torch.int32, device=dev)
+            greedy = self.sample_params(temperature=0.0, top_no=0.0)
+            st = states[0][0]
+            for step in range(n_steps):
+                if step > 0:
+                    st.max_ctx = states[0][2] + step - 1
+                    L.check(lib.valle_ar_decode(self._handle, C.byref(st), None, 1, L.ptr(last), ld, L.ptr(ws), ws.numel(), stream))
+                src, rows = (first_logits[0], 1) if step == 0 else (last, B)       # step 0: the batch is still the one utterance
+                L.check(lib.valle_beam_pick(L.ptr(src), src.stride(0), V, rows, B, C.byref(sp), L.ptr(seq), cap, L.ptr(seq_len),
+                                            L.ptr(proc), L.ptr(forced), L.ptr(ids), None, stream))
+                self._ar_sample_append(forced, V, seq, seq_len, [states[0][1][2]], stopped, scores, greedy, cap, step=step,
+                                       bump_ctx=step > 0)
+                if bool(stopped.all().item()):
+                    break
+            out = self._ar_finish(seq, seq_len, prefix, prefix_lens, prefix_context, start_slice, refine_on_stop, n_steps,
+                                  phns_list, lang_list, proms_list, return_logits, all_logits)
+            return out[:1]                                                        # ar_nar.py:865-867
         if cfg_strength <= 0:
             # step 0: sample from the prefill's last row, then chunks of cached steps
             st = states[0][0]

@@ -579,8 +579,9 @@ class Base:
         """Base.sample's kwargs (base.py:1288-1309) -> the C struct.  Samplers outside the built
         chain raise instead of being silently ignored."""
         for k in UNSUPPORTED_SAMPLERS:
-            if other.get(k):
-                raise NotImplementedError(f"sampling option {k!r} is not built on the HIP path")
+            if other.get(k) and not (k == "beam_width" and other[k] == 1):
+                raise NotImplementedError(f"sampling option {k!r} is not built on the HIP path"
+                                          + (" outside forward_ar" if k == "beam_width" else ""))
         if other.get("mirostat") is not None or other.get("attentions") is not None:
             raise NotImplementedError("mirostat / entropix sampling are not built on the HIP path")
         if min_temperature < 0:
