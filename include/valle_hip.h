@@ -172,6 +172,22 @@ int valle_sample(const float* logits, int ld, int vocab, int rows, const int32_t
                  const int32_t* prev_len, int nar_mode, const valle_sample_params* params,
                  int32_t* ids, float* scores, void* stream);
 
+/* Mirostat state of one utterance (samplers.py:197-238; the dict the reference threads through Base.sample(mirostat=[...])):
+ * in: n, tau, eta and the running values (max_surprise = 2 tau, the others 0 on a fresh state); out: the running values,
+ * the drawn token and k = the size of the candidate set of this draw (-1: the reference's compute_k divides by zero on
+ * these logits -- fewer than 101 columns with non-zero probability -- and the state is left as it was). */
+typedef struct {
+    double n, tau, eta, max_surprise, error_surprise, running_total_surprise, index_surprise;
+    int32_t token, k;
+} valle_mirostat_state;
+
+/* valle_sample whose final pick is the mirostat draw (models/base.py:1404-1407): after the sampler chain, row r (one row
+ * per utterance: row_item == NULL or rows == utterances) is sorted, k = compute_k(softmax, n, max_surprise) + 1, the token is
+ * drawn from the softmax of the k largest logits (Philox stream of params), states[r] is updated.  vocab >= 101. */
+int valle_sample_mirostat(const float* logits, int ld, int vocab, int rows, const int32_t* prev, const int32_t* prev_off,
+                          const int32_t* prev_len, const valle_sample_params* params, valle_mirostat_state* states,
+                          int32_t* ids, float* scores, void* stream);
+
 /* Classifier-free guidance (samplers.py:177-191) on fp32 logits, per utterance i over its
  * rows [row_off[i], row_off[i+1]): s = neg + (pos - neg) * strength; if rescale > 0,
  * s *= rescale * std(pos)/std(s) + (1 - rescale) with std the unbiased std over ALL

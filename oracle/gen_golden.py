@@ -886,6 +886,32 @@ def scen_tiny_beam():
     raise RuntimeError("tiny_beam: no seed with a safe candidate order")
 
 
+def scen_mirostat_kat():
+    """Base.sample(mirostat=[state, ...]) of the reference (models/base.py:1404-1407, samplers.py:197-238) on seeded logits:
+    three successive calls on three utterances, the states threaded through; top_no is 0 (at its default of 1.0 the
+    filter leaves -inf behind and compute_k divides by zero).  The draws are torch.multinomial's under manual_seed."""
+    ref = rh.load_reference()
+    model, mcfg = get_ref_model("tiny")
+    g = torch.Generator().manual_seed(77)
+    d = {}
+    states = [{"n": 1024, "tau": 3.0, "eta": 0.1}, {"n": 1024, "tau": 5.0, "eta": 0.3}, {"n": 1024, "tau": 2.0, "eta": 0.05}]
+    prevs = [torch.randint(0, 1024, (n,), generator=g) for n in (5, 9, 2)]
+    torch.manual_seed(123)
+    for call in range(3):
+        lg = [torch.randn(1, 1025, generator=g) * s_ for s_ in (2.0, 3.5, 1.2)]
+        d[f"logits_{call}"] = torch.cat(lg)
+        out = model.sample(logits=[l.clone() for l in lg], prev_list=[p.clone() for p in prevs], temperature=0.9, top_no=0.0,
+                           repetition_penalty=1.1, mirostat=states)
+        d[f"ids_{call}"] = torch.stack([t.reshape(()) for t in out.ids])
+        for k in ("max_surprise", "error_surprise", "running_total_surprise", "index_surprise"):
+            d[f"{k}_{call}"] = np.array([float(st[k]) for st in states])
+        prevs = [torch.cat([p, t.reshape(1)]) for p, t in zip(prevs, out.ids)]
+    for i, p in enumerate(prevs):
+        d[f"prev_final_{i}"] = p
+    d["prev_len0"] = np.array([5, 9, 2])
+    save("mirostat_kat", **d)
+
+
 def scen_full_b3():
     mk = lambda s: synth_batch(s, 3, n_phn=30, n_prom=60, ragged=True)
     ar_nar_scenario("full_b3", "full", mk, 61, steps=12)
@@ -939,6 +965,7 @@ SCENARIOS = {
     "tiny_lora": scen_tiny_lora,
     "qnt_kat": scen_qnt_kat,
     "tiny_beam": scen_tiny_beam,
+    "mirostat_kat": scen_mirostat_kat,
     "full_b1": scen_full_b1,
     "long": scen_long,
     "full_b3": scen_full_b3,

@@ -241,10 +241,43 @@ def cfg_combine(pos_logits, null_logits, strength, lens, rescale=0.0):
     return pos_logits
 
 
+def mirostat_sample(logits, state, generator=None, forced_index=None):
+    """samplers.py:197-238 on one utterance's processed logits (rows, V): the LAST row is sorted, k comes from the
+    Zipf-exponent estimate over the 100 leading probability ratios (Python float arithmetic on the fp32 softmax), the
+    token is drawn from the softmax of the k + 1 largest logits, the state dict is updated in place and returned.
+    forced_index (tests): the position in the sorted order to take instead of drawing."""
+    def compute_k(prob, n, tau):
+        num = den = 0.0
+        for i in range(100):
+            b = prob[i] / prob[i + 1]
+            t = (i + 2) / (i + 1)
+            num += math.log(b) * math.log(t)
+            den += math.log(t) ** 2
+        s_hat = num / den
+        eps = s_hat - 1
+        return round(((eps * (2 ** tau)) / (1 - n ** (-eps))) ** (1 / s_hat))
+    state.setdefault("max_surprise", state["tau"] * 2)
+    state.setdefault("error_surprise", 0)
+    state.setdefault("running_total_surprise", 0)
+    sorted_logits, sorted_indices = torch.sort(logits[-1, :], descending=True)
+    prob_original = torch.softmax(sorted_logits, dim=-1).tolist()
+    k = compute_k(prob_original, state["n"], state["max_surprise"]) + 1
+    prob_topk = torch.softmax(sorted_logits[0:k], dim=0)
+    i = torch.multinomial(prob_topk, num_samples=1, replacement=True, generator=generator) if forced_index is None \
+        else torch.tensor([forced_index])
+    state["index_surprise"] = math.log2(1 / prob_original[i])
+    state["running_total_surprise"] += state["index_surprise"]
+    state["error_surprise"] = state["index_surprise"] - state["tau"]
+    state["max_surprise"] -= state["eta"] * state["error_surprise"]
+    state["token"] = sorted_indices[i]
+    state["k"] = k                                                          # (not in the reference's dict: for the tests)
+    return state
+
+
 def sample(logits, prev_list=None, quant_levels=None, *, causal_size=1, stop_token=1024, generator=None,
            temperature=1.0, min_temperature=-1.0, top_k=-100, top_p=1.0, min_p=0.0,
            repetition_penalty=1.0, repetition_penalty_decay=0.0, length_penalty=0.0, top_no=1.0,
-           dry_multiplier=0.0, dry_base=1.75, dry_allowed_length=2, beam_width=0, **_unused):
+           dry_multiplier=0.0, dry_base=1.75, dry_allowed_length=2, beam_width=0, mirostat=None, **_unused):
     """Base.sample (base.py:1280-1430), basic branch and beam branch (no mirostat / entropix).
     Returns (ids, processed_logits, scores)."""
     if min_temperature < 0:
@@ -272,6 +305,9 @@ def sample(logits, prev_list=None, quant_levels=None, *, causal_size=1, stop_tok
         logits = [top_n_sigma(l) for l in logits]
     if dry_multiplier > 0.0 and prev_list is not None:                       # :1399-1400
         logits = [dry_sampling(l, p, dry_multiplier, dry_base, dry_allowed_length) for l, p in zip(logits, prev_list)]
+    if mirostat is not None:                                                 # base.py:1404-1407
+        states = [mirostat_sample(l, st, generator) for l, st in zip(logits, mirostat)]
+        return [st["token"] for st in states], logits, states
     if beam_width > 1:                                                       # base.py:1412-1415 with samplers.py:148-160: the
         flat = torch.cat(logits)                                             # beam_width best (row, token) pairs of ALL rows,
         V = flat.shape[-1]                                                   # best first; candidate i goes to sequence i

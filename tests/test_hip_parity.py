@@ -340,6 +340,53 @@ def test_tiny_cfg(gpu_device):
     _ar_nar("tiny", "tiny_cfg")
 
 
+def test_mirostat_state_and_draws(gpu_device):
+    """Base.sample(mirostat=[state, ...]) on the HIP path (valle_sample_mirostat; reference models/base.py:1404-1407,
+    samplers.py:197-238).  The draw itself comes from the Philox stream (torch.multinomial's cannot be reproduced), so per
+    call and utterance: k == the reference restatement's on the same state, the token lies among the k + 1 largest logits,
+    and the four running values == the restatement's when it is made to take the same token.  The restatement is pinned
+    bit for bit by the reference's own run (tests/test_oracle_vs_golden.py::test_mirostat_known_answers).  Then 600 draws
+    of one row: the most likely token comes up at its softmax-of-top-k rate."""
+    import copy
+    import valle_oracle as vo
+    m = hip_model("tiny")
+    z = load_golden("mirostat_kat")
+    states = [{"n": 1024, "tau": 3.0, "eta": 0.1}, {"n": 1024, "tau": 5.0, "eta": 0.3}, {"n": 1024, "tau": 2.0, "eta": 0.05}]
+    prevs = [torch.from_numpy(z[f"prev_final_{i}"])[: int(n)] for i, n in enumerate(z["prev_len0"])]
+    kw = dict(temperature=0.9, top_no=0.0, repetition_penalty=1.1)
+    for call in range(3):
+        lg = [torch.from_numpy(z[f"logits_{call}"][i:i + 1]) for i in range(3)]
+        before = copy.deepcopy(states)
+        out = m.sample(logits=[l.to(gpu_device) for l in lg], prev_list=prevs, mirostat=states, seed=11 + call, **kw)
+        assert out.scores is not None and all(st is s for st, s in zip(states, out.scores))
+        _, processed, _ = vo.sample(lg, prev_list=prevs, temperature=0.0, **{k: v for k, v in kw.items() if k != "temperature"})
+        processed = [p / 0.9 for p in processed]                                # the chain's temperature step, then no pick
+        for i in range(3):
+            tok = int(out.ids[i].item())
+            order = torch.sort(processed[i][-1], descending=True).indices.tolist()
+            pos = order.index(tok)
+            want = vo.mirostat_sample(processed[i], dict(before[i]), forced_index=pos)
+            assert states[i]["k"] == want["k"] and pos < want["k"], (call, i, states[i]["k"], want["k"], pos)
+            for k in ("max_surprise", "error_surprise", "running_total_surprise", "index_surprise"):
+                assert abs(states[i][k] - want[k]) <= 1e-5 * max(1.0, abs(want[k])), (call, i, k, states[i][k], want[k])
+        prevs = [torch.cat([p, t.reshape(1).cpu()]) for p, t in zip(prevs, out.ids)]
+    # draw statistics on one row
+    lg = [torch.from_numpy(z["logits_0"][0:1]).to(gpu_device)]
+    base = {"n": 1024, "tau": 3.0, "eta": 0.1}
+    ref_state = vo.mirostat_sample(lg[0].cpu() / 0.9, dict(base), forced_index=0)
+    srt = torch.sort(lg[0].cpu()[-1] / 0.9, descending=True)
+    p0 = float(torch.softmax(srt.values[: ref_state["k"]], dim=0)[0])
+    hits, n = 0, 600
+    for s_ in range(n):
+        st = [dict(base)]
+        out = m.sample(logits=lg, prev_list=None, mirostat=st, seed=1000 + s_, temperature=0.9, top_no=0.0)
+        hits += int(out.ids[0].item()) == int(srt.indices[0])
+    sigma = (p0 * (1 - p0) / n) ** 0.5
+    assert abs(hits / n - p0) < 4.5 * sigma + 1e-3, (hits / n, p0)
+    with pytest.raises(ZeroDivisionError):                                       # default top_no = 1.0 leaves -inf behind: the reference's
+        m.sample(logits=lg, prev_list=None, mirostat=[dict(base)], temperature=0.9)   # compute_k divides by zero (samplers.py:202)
+
+
 def test_tiny_beam_search(gpu_device):
     """beam_width=3 on one utterance without a language list (the only form the version-5 reference can run,
     models/ar_nar.py:821-842, :865-867; models/base.py:1412-1415): codes == the reference's."""

@@ -172,6 +172,26 @@ def test_tiny_cfg():
     _ar_nar("tiny", "tiny_cfg")
 
 
+def _mirostat_states():
+    return [{"n": 1024, "tau": 3.0, "eta": 0.1}, {"n": 1024, "tau": 5.0, "eta": 0.3}, {"n": 1024, "tau": 2.0, "eta": 0.05}]
+
+
+def test_mirostat_known_answers():
+    """Base.sample(mirostat=[...]) (base.py:1404-1407, samplers.py:197-238): tokens and the four running values of three
+    threaded calls == the reference's (the draws are torch.multinomial's under the same manual_seed)."""
+    z = load_golden("mirostat_kat")
+    states = _mirostat_states()
+    prevs = [torch.from_numpy(z[f"prev_final_{i}"])[: int(n)] for i, n in enumerate(z["prev_len0"])]
+    torch.manual_seed(123)
+    for call in range(3):
+        lg = [torch.from_numpy(z[f"logits_{call}"][i:i + 1]) for i in range(3)]
+        ids, _, out = vo.sample(lg, prev_list=prevs, temperature=0.9, top_no=0.0, repetition_penalty=1.1, mirostat=states)
+        np.testing.assert_array_equal(torch.stack([t.reshape(()) for t in ids]).numpy(), z[f"ids_{call}"])
+        for k in ("max_surprise", "error_surprise", "running_total_surprise", "index_surprise"):
+            np.testing.assert_allclose([st[k] for st in states], z[f"{k}_{call}"], rtol=1e-12, atol=0)
+        prevs = [torch.cat([p, t.reshape(1)]) for p, t in zip(prevs, ids)]
+
+
 def test_tiny_beam_search():
     """Beam search as the reference runs it (no language list; ar_nar.py:821-842, base.py:1412-1415)."""
     z = load_golden("tiny_beam")

@@ -41,6 +41,11 @@ class LayerWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ln1", "w_qkv", "w_o", "ln2", "w_gu", "w_down", "p_o", "p_down", "pn_qkv", "pn_gu", "f_qkv", "f_gu")]
 
 
+class MirostatState(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("n", "tau", "eta", "max_surprise", "error_surprise", "running_total_surprise",
+                                          "index_surprise")] + [("token", C.c_int32), ("k", C.c_int32)]
+
+
 class ARState(C.Structure):
     _fields_ = [
         ("B", C.c_int), ("max_steps", C.c_int),
@@ -62,6 +67,8 @@ SIGNATURES = {
     "valle_gemm_normed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "valle_beam_pick": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p]),
+    "valle_sample_mirostat": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p]),
     "valle_rope_kv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                               c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "valle_attn_prefill": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

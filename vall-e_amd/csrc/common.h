@@ -92,6 +92,7 @@ struct SampleArgs {
     int early_exit;             // rows whose utterance has stopped[] set append nothing and keep seq_len / ctx_len
     int prev_is_seq;            // prev tokens of row i = seq[i*seq_cap .. + seq_len[i])
     uint64_t step;              // added to the Philox offset
+    valle_mirostat_state* mirostat;   // per row: the pick is the mirostat draw (samplers.py:197-238)
     float* proc_out;            // beam search: the processed logits of row r go to proc_out[r*ld ..] and nothing is picked
     // optional fused prologue of the NEXT decode step (wave-streaming path): embed the sampled token into the
     // fragment-order x and its RoPE position

@@ -319,7 +319,74 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
     for (int v = tid; v < V; v += SAMP_THREADS) se += expf(vals[v] - mx);
     se = block_reduce_sum(se, red);   // all -inf: exp(nan) -> nan, like the reference's softmax
     int tok;
-    if (a.p.temperature <= 0.0f) {
+    if (a.mirostat != nullptr) {
+        // samplers.py:197-238.  Descending sort of the processed row (bitonic, in LDS; equal logits: lower index first)
+        for (int v = tid; v < SAMP_MAXV; v += SAMP_THREADS) { skey[v] = v < V ? vals[v] : -INFINITY; sidx[v] = v; }
+        __syncthreads();
+        for (int k2 = 2; k2 <= SAMP_MAXV; k2 <<= 1)
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < SAMP_MAXV; t += SAMP_THREADS) {
+                    const int u = t ^ j;
+                    if (u > t) {
+                        const float x = skey[t], y = skey[u];
+                        const int xi = sidx[t], yi = sidx[u];
+                        const bool x_first = (x > y) || (x == y && xi < yi) || (y != y && x == x);
+                        const bool desc = (t & k2) == 0;
+                        if (desc ? !x_first : x_first) { skey[t] = y; skey[u] = x; sidx[t] = yi; sidx[u] = xi; }
+                    }
+                }
+                __syncthreads();
+            }
+        // prob_original = softmax(sorted) in fp32 (mx, se of the whole row are the sorted row's too)
+        __shared__ int s_k;
+        __shared__ float s_sek;
+        valle_mirostat_state* st = a.mirostat + item;
+        if (tid == 0) {
+            double num = 0.0, den = 0.0;
+            bool zero = V < 101;
+            for (int i = 0; i < 100 && !zero; ++i) {                       // compute_k (:198-211), Python float arithmetic
+                const double p0 = (double)(expf(skey[i] - mx) / se), p1 = (double)(expf(skey[i + 1] - mx) / se);
+                if (p1 == 0.0) { zero = true; break; }
+                const double b = p0 / p1, t = (double)(i + 2) / (double)(i + 1);
+                num += log(b) * log(t);
+                den += log(t) * log(t);
+            }
+            int k = -1;
+            if (!zero) {
+                const double s_hat = num / den, eps = s_hat - 1.0;
+                const double kf = pow((eps * pow(2.0, st->max_surprise)) / (1.0 - pow(st->n, -eps)), 1.0 / s_hat);
+                k = (kf == kf && kf < 1e9 && kf > -1e9) ? (int)rint(kf) + 1 : V;   // round(): half to even, like rint
+                k = k < 1 ? 1 : (k > V ? V : k);
+            }
+            s_k = k;
+        }
+        __syncthreads();
+        const int k = s_k;
+        if (k < 0) {                                                   // ZeroDivisionError in the reference: nothing is drawn
+            if (tid == 0) { st->k = -1; st->token = 0; a.ids[row] = 0; if (a.scores) a.scores[row] = 0.f; }
+            return;
+        }
+        float sek = 0.f;
+        for (int i = tid; i < k; i += SAMP_THREADS) sek += expf(skey[i] - mx);
+        sek = block_reduce_sum(sek, red);
+        if (tid == 0) {
+            // draw from softmax(sorted[:k]) by inverse CDF over the sorted order (torch.multinomial's stream is torch's own)
+            const float u = philox_uniform(a.p.seed, a.p.offset + a.step, (uint32_t)row) * sek;
+            float run = 0.f; int pick = k - 1;
+            for (int i = 0; i < k; ++i) { run += expf(skey[i] - mx); if (run >= u) { pick = i; break; } }
+            const double p_pick = (double)(expf(skey[pick] - mx) / se);
+            const double surprise = log2(1.0 / p_pick);
+            st->index_surprise = surprise;
+            st->running_total_surprise += surprise;
+            st->error_surprise = surprise - st->tau;
+            st->max_surprise -= st->eta * st->error_surprise;
+            st->token = sidx[pick];
+            st->k = k;
+            s_flag = sidx[pick];
+        }
+        __syncthreads();
+        tok = s_flag;
+    } else if (a.p.temperature <= 0.0f) {
         int best = 1 << 30;
         for (int v = tid; v < V; v += SAMP_THREADS) if (vals[v] == mx && v < best) best = v;
         if (tid == 0) s_flag = 1 << 30;
@@ -501,7 +568,7 @@ static bool sample_is_plain_greedy(const SampleArgs& a) {
 }
 
 int valle_sample_launch(const SampleArgs& a, int rows, hipStream_t s) {
-    if (a.proc_out == nullptr && sample_is_plain_greedy(a)) {
+    if (a.proc_out == nullptr && a.mirostat == nullptr && sample_is_plain_greedy(a)) {
         if (a.vocab <= 64 * 17) sample_greedy_wave_kernel<17><<<rows, 64, 0, s>>>(a);
         else sample_greedy_wave_kernel<32><<<rows, 64, 0, s>>>(a);
     } else {
@@ -525,6 +592,20 @@ extern "C" int valle_sample(const float* logits, int ld, int vocab, int rows, co
     a.logits = logits; a.ld = ld; a.vocab = vocab; a.row_item = row_item; a.row_in_item = row_in_item;
     a.prev = prev; a.prev_off = prev_off; a.prev_len = prev_len; a.nar_mode = nar_mode; a.p = *params;
     a.ids = ids; a.scores = scores;
+    return valle_sample_launch(a, rows, (hipStream_t)stream);
+}
+
+extern "C" int valle_sample_mirostat(const float* logits, int ld, int vocab, int rows, const int32_t* prev,
+                                     const int32_t* prev_off, const int32_t* prev_len, const valle_sample_params* params,
+                                     valle_mirostat_state* states, int32_t* ids, float* scores, void* stream) {
+    VALLE_REQUIRE(logits && params && ids && states, VALLE_E_ARG, "valle_sample_mirostat: null pointer");
+    VALLE_REQUIRE(vocab >= 101 && vocab <= SAMP_MAXV && ld >= vocab, VALLE_E_ARG, "valle_sample_mirostat: vocab %d (101..%d), ld %d", vocab, SAMP_MAXV, ld);
+    VALLE_REQUIRE(prev == nullptr || (prev_off && prev_len), VALLE_E_ARG, "valle_sample_mirostat: prev needs prev_off/prev_len");
+    VALLE_REQUIRE(params->rep_pen_passes == 1 && params->filter_passes >= 0 && params->filter_passes <= 1, VALLE_E_ARG, "valle_sample_mirostat: rep_pen_passes / filter_passes");
+    if (rows == 0) return VALLE_OK;
+    SampleArgs a{};
+    a.logits = logits; a.ld = ld; a.vocab = vocab; a.prev = prev; a.prev_off = prev_off; a.prev_len = prev_len; a.nar_mode = 0;
+    a.p = *params; a.ids = ids; a.scores = scores; a.mirostat = states;
     return valle_sample_launch(a, rows, (hipStream_t)stream);
 }
 

@@ -582,8 +582,11 @@ class Base:
             if other.get(k) and not (k == "beam_width" and other[k] == 1):
                 raise NotImplementedError(f"sampling option {k!r} is not built on the HIP path"
                                           + (" outside forward_ar" if k == "beam_width" else ""))
-        if other.get("mirostat") is not None or other.get("attentions") is not None:
-            raise NotImplementedError("mirostat / entropix sampling are not built on the HIP path")
+        if other.get("mirostat") is not None:
+            raise NotImplementedError("an explicit mirostat state list goes through Base.sample (not the generation loops, "
+                                      "which never pass one in the reference either: ar_nar.py:804-808)")
+        if other.get("attentions") is not None:
+            raise NotImplementedError("entropix sampling is not built on the HIP path")
         if min_temperature < 0:
             min_temperature = temperature
         if abs(float(temperature) - float(min_temperature)) < 0.001:          # base.py:1389: dynamic temperature off
@@ -609,9 +612,50 @@ class Base:
         ld = _round_up(V, 8)
         flat = torch.zeros((int(off[-1]), ld), dtype=torch.float32, device=self.device)
         flat[:, :V] = torch.cat([r.to(self.device, torch.float32) for r in rows])
+        mirostat = sampling_kwargs.pop("mirostat", None)
+        if mirostat is not None:
+            return self._sample_mirostat(flat, V, logits, rows, prev_list, mirostat, self.sample_params(**sampling_kwargs))
         ids, scores = self.sample_rows(flat, V, off, prev_list, nar_mode=nar, params=self.sample_params(**sampling_kwargs))
         cut = lambda t: [t[off[i]:off[i + 1]] for i in range(B)]
         return Sampled(cut(ids.long()), logits, cut(scores), None)
+
+    def _sample_mirostat(self, flat, V, logits, rows, prev_list, mirostat, params):
+        """Base.sample(mirostat=[state, ...]) (base.py:1404-1407, samplers.py:197-238): one state dict per utterance, the
+        utterance's last row is drawn from, the dicts are updated in place and returned as ``scores`` -- as the reference
+        does.  The draw uses the Philox stream of ``seed`` (torch.multinomial's stream cannot be reproduced)."""
+        lib = L.load()
+        B = len(rows)
+        if any(r.shape[0] != 1 for r in rows):                                   # mirostat_sample reads logits[-1, :]
+            keep = np.cumsum([r.shape[0] for r in rows]) - 1
+            flat = flat[torch.from_numpy(keep).to(self.device)].contiguous()
+        host = (L.MirostatState * B)()
+        for i, st in enumerate(mirostat):
+            st.setdefault("max_surprise", st["tau"] * 2)                          # samplers.py:213-220
+            st.setdefault("error_surprise", 0)
+            st.setdefault("running_total_surprise", 0)
+            host[i] = L.MirostatState(float(st["n"]), float(st["tau"]), float(st["eta"]), float(st["max_surprise"]),
+                                      float(st["error_surprise"]), float(st["running_total_surprise"]), 0.0, 0, 0)
+        nbytes = C.sizeof(host)
+        dev_states = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.device)
+        prev = prev_off = prev_len = None
+        if prev_list is not None:
+            pl = [(_np(p) if _np(p).ndim == 1 else _np(p)[:, -1]).astype(np.int32) for p in prev_list]
+            lens = np.array([len(p) for p in pl], dtype=np.int32)
+            prev_off = self._i32(np.concatenate(([0], np.cumsum(lens)[:-1])))
+            prev_len = self._i32(lens)
+            prev = self._i32(np.concatenate(pl) if lens.sum() else np.zeros(1, np.int32))
+        ids = torch.empty(B, dtype=torch.int32, device=self.device)
+        scores = torch.empty(B, dtype=torch.float32, device=self.device)
+        L.check(lib.valle_sample_mirostat(L.ptr(flat), flat.shape[1], V, B, L.ptr(prev), L.ptr(prev_off), L.ptr(prev_len),
+                                          C.byref(params), L.ptr(dev_states), L.ptr(ids), L.ptr(scores), L.stream_ptr(self.device)))
+        back = (L.MirostatState * B).from_buffer_copy(dev_states.cpu().numpy().tobytes()[:nbytes])
+        for st, b in zip(mirostat, back):
+            if b.k < 0:
+                raise ZeroDivisionError("float division by zero")               # compute_k, samplers.py:202 (e.g. top_no left -inf behind)
+            st.update(index_surprise=b.index_surprise, running_total_surprise=b.running_total_surprise,
+                      error_surprise=b.error_surprise, max_surprise=b.max_surprise,
+                      token=torch.tensor([b.token], device=self.device), k=b.k)
+        return Sampled([st["token"] for st in mirostat], logits, list(mirostat), None)
 
     def sample_rows(self, logits, vocab, row_off, prev_list, nar_mode, params, dev=None):
         """valle_sample over packed logits rows; row_off = per-utterance row offsets (B+1).
