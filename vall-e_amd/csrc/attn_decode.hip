@@ -126,6 +126,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(const bf16* _
     const int b = blockIdx.x, h = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 3, sub = lane & 7;
+    // q first: vector loads return in order, so a q requested behind the K/V rows would arrive behind all of them and the
+    // first score could not start before the whole pass has landed
+    u32x4 qb = *reinterpret_cast<const u32x4*>(pQ + (size_t)b * a.q_row_stride + h * 64 + (lane & 7) * 8);
     const int sl = pSlot ? pSlot[b] : b;
     const int ctx = pCtx[b];
     if (ctx < 0) return;        // finished utterance (valle_ar_state.early_exit stores ~ctx_len): the whole workgroup leaves
@@ -138,7 +141,6 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(const bf16* _
     const bf16* vb = pV + base;
     u32x4 kA[MAXC], vA[MAXC], kB[MAXC], vB[MAXC];
     attn_dec_issue<MAXC, NW>(kb, vb, 0, wave, g, bound, kA, vA);
-    u32x4 qb = *reinterpret_cast<const u32x4*>(pQ + (size_t)b * a.q_row_stride + h * 64 + sub * 8);
     {   // q * 1/sqrt(64): exact in bf16
         bf16x8 qv = __builtin_bit_cast(bf16x8, qb);
 #pragma unroll
