@@ -415,7 +415,9 @@ __global__ __launch_bounds__(256) void gemm_glds_n64_bf16_kernel(const bf16* __r
 // buffer during the first three read slots of tile t -- that buffer's last fragment reads (tile t-1) were
 // waited for (lgkmcnt(0) before the barrier that ends a read slot) before tile t began -- and is waited for
 // (vmcnt(0)) in the 4th read slot, two barriers before its first read.
-template <int EPI, bool NORM = false>
+// MQR = m rows per wave: 64 (256-row tiles) or 48 (192-row tiles: the second B half is one 16-row tile instead of two --
+// for row counts whose 256-row tiling leaves CUs idle, see gemm_glds_dispatch)
+template <int EPI, bool NORM = false, int MQR = 64>
 __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W,
                                                               const void* __restrict__ bias, const bf16* resid,
                                                               void* Cout, int M, int N, int K, int ldc, float eps = 0.f) {
@@ -425,20 +427,22 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
     const int grp = wave >> 2, wi = wave & 3;
     const int nh = wi & 1, mq = (wi >> 1) + 2 * grp;                       // n half (128 rows), m quarter (64 rows)
     const int fr = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.x * 256, m0 = blockIdx.y * 256;
+    static_assert(MQR == 64 || (MQR == 48 && !NORM), "m rows per wave");
+    constexpr int TMR = 4 * MQR, MJ = MQR / 16, PPW = (32 + TMR / 8) / 8;    // tile rows, 16-row m tiles per wave, pieces per wave
+    const int n0 = blockIdx.x * 256, m0 = blockIdx.y * TMR;
 
-    f32x4 acc[8][4];
+    f32x4 acc[8][MJ];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // staging: a K-tile is 64 pieces of 8 rows (W: 0..31, X: 32..63); this wave issues pieces wave*8 .. +7
     const bf16* src[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int piece = wave * 8 + j;
-        const int row = piece * 8 + (lane >> 3);                           // 0..255 W rows, 256..511 X rows
+        const int piece = wave * PPW + (j < PPW ? j : PPW - 1);
+        const int row = piece * 8 + (lane >> 3);                           // 0..255 W rows, 256..256+TMR-1 X rows
         const int ch = (lane & 7) ^ (row & 7);
         if (piece < 32) { int n = n0 + row; n = n < N ? n : N - 1; src[j] = W + (size_t)n * K + ch * 8; }
         else { int m = m0 + row - 256; m = m < M ? m : M - 1; src[j] = X + (size_t)m * K + ch * 8; }
@@ -446,13 +450,13 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
     auto stage_part = [&](int kt, int buf, int j0, int j1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (j >= j0 && j < j1)
-                __builtin_amdgcn_global_load_lds(src[j] + kt * 64, (lds_void*)&lds[buf * 65536 + (wave * 8 + j) * 1024], 16, 0, 0);
+            if (j >= j0 && j < j1 && j < PPW)
+                __builtin_amdgcn_global_load_lds(src[j] + kt * 64, (lds_void*)&lds[buf * 65536 + (wave * PPW + j) * 1024], 16, 0, 0);
     };
     auto stage = [&](int kt, int buf) { stage_part(kt, buf, 0, 8); };
     // fragment addressing: row = const + fr, so (row & 7) == (fr & 7) and the swizzle depends on the k-half only
     const int sw0 = ((fq ^ (fr & 7)) << 4), sw1 = (((4 + fq) ^ (fr & 7)) << 4);
-    const int abase = (nh * 128 + fr) * 128, bbase = (256 + mq * 64 + fr) * 128;
+    const int abase = (nh * 128 + fr) * 128, bbase = (256 + mq * MQR + fr) * 128;
     bf16x8 A[4][2], B0[2][2], B1[2][2];
     auto read_a = [&](const char* L, int i) {
 #pragma unroll
@@ -464,6 +468,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
     auto read_b = [&](const char* L, int j, bf16x8 (&Bf)[2][2]) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
+            if (j * 2 + ct >= MJ) continue;
             Bf[ct][0] = *reinterpret_cast<const bf16x8*>(L + bbase + (j * 32 + ct * 16) * 128 + sw0);
             Bf[ct][1] = *reinterpret_cast<const bf16x8*>(L + bbase + (j * 32 + ct * 16) * 128 + sw1);
         }
@@ -483,7 +488,8 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
             for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
-                    acc[i * 4 + rt][j * 2 + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[rt][hf], Bf[ct][hf], acc[i * 4 + rt][j * 2 + ct], 0, 0, 0);
+                    if (j * 2 + ct < MJ)
+                        acc[i * 4 + rt][j * 2 + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[rt][hf], Bf[ct][hf], acc[i * 4 + rt][j * 2 + ct], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
 #define PP_END_READ()  do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
             for (int i = 0; i < 8; ++i) acc[i][j] *= rinv;
         }
     }
-    gemm_epilogue<bf16, EPI, 8, 4>(acc, n0 + nh * 128, m0 + mq * 64, fr, fq, bias, resid, Cout, M, N, ldc);
+    gemm_epilogue<bf16, EPI, 8, MJ>(acc, n0 + nh * 128, m0 + mq * MQR, fr, fq, bias, resid, Cout, M, N, ldc);
 }
 
 static int gemm_glds_dispatch(const void* A, const void* W, const void* bias, const void* resid, void* C,
@@ -541,8 +547,18 @@ static int gemm_glds_dispatch(const void* A, const void* W, const void* bias, co
     // down_proj (K = d_ff >= 2048, narrow N): 64 K-tiles amortise the 256^2 ping-pong kernel's fill and epilogue even
     // though N = 1024 gives only 4 x ceil(M/256) workgroups (measured 113.6 vs 133.5 us at M = 12,176)
     if (epi == VALLE_EPI_RESID && K >= 2048 && M >= 2048 && N >= 256) {
-        dim3 g256(ceil_div(N, 256), ceil_div(M, 256));
-        gemm_pp256_bf16_kernel<VALLE_EPI_RESID><<<g256, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
+        // one workgroup per CU: what counts is the number of rounds of 256 workgroups.  192-row tiles do 3/4 of the MFMA work
+        // of a 256-row tile in ~0.85 of its time; they win where they save a round or fill idle CUs (M = 12,176, N = 1,024:
+        // 192 workgroups of 256 rows leave 64 CUs idle, 256 workgroups of 192 rows fill the chip)
+        const int nx = ceil_div(N, 256);
+        const float r256 = (float)ceil_div(nx * ceil_div(M, 256), 256), r192 = 0.85f * (float)ceil_div(nx * ceil_div(M, 192), 256);
+        if (r192 < r256) {
+            dim3 g192(nx, ceil_div(M, 192));
+            gemm_pp256_bf16_kernel<VALLE_EPI_RESID, false, 48><<<g192, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
+        } else {
+            dim3 g256(nx, ceil_div(M, 256));
+            gemm_pp256_bf16_kernel<VALLE_EPI_RESID><<<g256, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
+        }
         VALLE_LAUNCH_CHECK();
         return VALLE_OK;
     }
