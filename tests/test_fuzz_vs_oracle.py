@@ -1,0 +1,143 @@
+"""Randomised differential test: the HIP path (fp32, tiny model) against the oracle over option combinations that no
+single golden covers together -- batch shape, prompt / text lengths, guidance, prefixes, penalties, filters, early exit,
+chunking, LoRA -- greedy, so that results are comparable.  A difference is only accepted when the oracle's own top-2 margin
+at the first differing decision is below the fp32 logit error (a near tie); anything else fails."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import model_cfg, synth_weights
+
+pytestmark = pytest.mark.gpu
+
+TIE = 2e-4
+
+
+def _models(kind, lora):
+    import valle_oracle as vo
+    from vall_e_amd.models import get_model
+    from vall_e_amd.weights import synth_lora_state_dict
+    cfg = model_cfg(kind)
+    sd = synth_weights(kind)
+    m = get_model(cfg, training=False)
+    m.load_state_dict(sd)
+    o = vo.Oracle(cfg, sd)
+    if lora is not None:
+        rank, alpha, levels = lora
+        t = synth_lora_state_dict(cfg, rank)
+        m.load_lora(t, rank=rank, alpha=alpha, rvq_levels=levels)
+        o.load_lora(t, rank, alpha, levels)
+    return m.to("cuda:0", torch.float32), o
+
+
+def _first_diff(a, b):
+    n = min(len(a), len(b))
+    for i in range(n):
+        if int(a[i]) != int(b[i]):
+            return i
+    return n if len(a) != len(b) else -1
+
+
+@pytest.mark.parametrize("seed", list(range(48)))
+def test_random_option_mix_matches_oracle(gpu_device, seed):
+    from vall_e_amd.synth import synth_batch
+    rng = np.random.default_rng(1000 + seed)
+    kind = ["tiny", "tiny", "tiny_nc", "tiny_upi", "tiny_nosum"][int(rng.integers(5))]
+    lora = (4, 8, [(), (0,), (0, 2), (1, 3)][int(rng.integers(4))]) if kind == "tiny" and rng.random() < 0.4 else None
+    m, o = _models(kind, lora)
+    B = int(rng.integers(1, 6))
+    phns, proms, langs = synth_batch(int(rng.integers(1 << 20)), B, n_phn=int(rng.integers(4, 24)),
+                                     n_prom=int(rng.integers(3, 40)), ragged=bool(rng.random() < 0.7))
+    steps = int(rng.integers(1, 14))
+    kw = {}
+    if rng.random() < 0.35:
+        kw["cfg_strength"] = float(rng.choice([1.5, 3.0]))
+    if rng.random() < 0.3:
+        kw["repetition_penalty"] = float(rng.choice([1.1, 1.3])); kw["repetition_penalty_decay"] = float(rng.choice([0.0, 0.25]))
+    if rng.random() < 0.25:
+        kw["length_penalty"] = float(rng.choice([-0.5, 0.4]))
+    if rng.random() < 0.25:
+        kw["top_k"] = int(rng.choice([3, 20])); kw["top_no"] = 0.0
+    if rng.random() < 0.2:
+        kw["top_no"] = 0.0
+    mode = rng.random()
+    if mode < 0.15:
+        kw["input_prompt_prefix"] = True
+    elif mode < 0.3:
+        kw["prefix_silence"] = float(rng.choice([0.03, 0.1]))
+    hip_only = dict(step_chunk=int(rng.choice([1, 3, 32])), early_exit=bool(rng.random() < 0.5))
+    desc = f"seed {seed}: {kind} lora={lora} B={B} steps={steps} {kw} {hip_only}"
+    got = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=steps, temperature=0.0,
+            **kw, **hip_only)
+    want, logits = o.ar(phns, proms, langs, max_duration=steps, temperature=0.0, return_logits=True, **kw)
+    usable = []
+    for b in range(B):
+        g, w = got[b].cpu().numpy(), want[b].numpy()
+        d = _first_diff(g, w)
+        if d < 0:
+            usable.append(b)
+            continue
+        # the decision at response index d: the oracle's margin there (guided / filtered logits are not kept: be strict then)
+        margin = None
+        if not kw and d < len(logits):
+            row = logits[d][b]
+            v = torch.topk(row.float(), 2).values
+            margin = float(v[0] - v[1])
+        assert margin is not None and margin < TIE, f"{desc}\nutterance {b} differs at {d}: hip {g[:d+2]} oracle {w[:d+2]} margin {margin}"
+    # NAR levels on the utterances whose AR codes agree (same inputs on both sides), non-empty responses only
+    idx = [b for b in usable if len(want[b]) > 0]
+    if not idx or kw.get("input_prompt_prefix"):
+        return
+    if len(want[idx[0]]) == 8:                # reference quirk: a level-0 response of exactly n_resp_levels frames reads as
+        return                                # "all levels present" = training (ar_nar.py:927-931); both sides refuse it
+    nar_kw = {"cfg_strength": kw["cfg_strength"]} if "cfg_strength" in kw and rng.random() < 0.5 else {}
+    sub = lambda l: [l[b] for b in idx]
+    full = m(task_list=["tts"] * len(idx), phns_list=sub(phns), proms_list=sub(proms), lang_list=sub(langs),
+             resps_list=[got[b].clone() for b in idx], temperature=0.0, **nar_kw)
+    ref = o.nar(sub(phns), sub(proms), sub(langs), [want[b] for b in idx], temperature=0.0, **nar_kw)
+    bad = 0
+    for i in range(len(idx)):
+        g, w = full[i].cpu().numpy(), ref[i].numpy()
+        assert g.shape == w.shape, desc
+        # a flipped near tie at one level changes that row's later levels: count rows, not cells
+        bad += int((g != w).any(axis=1).sum())
+    total = sum(len(want[b]) for b in idx)
+    assert bad <= max(1, total // 50), f"{desc}\n{bad} of {total} NAR rows differ"
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_narlen_mix_matches_oracle(gpu_device, seed):
+    """NAR-len demasking (level 0 by iterative demasking, then the NAR levels) under random lengths, step counts, guidance
+    floors and score options, causal and non-causal models.  Demasking decisions are lowest-k cuts over scores: a single
+    near tie moves a position to another step, so agreement is asked of at least 95 % of the frames."""
+    from vall_e_amd.synth import synth_batch
+    rng = np.random.default_rng(5000 + seed)
+    kind = ["tiny", "tiny_nc", "tiny_nc_upi"][int(rng.integers(3))]
+    m, o = _models(kind, None)
+    B = int(rng.integers(1, 5))
+    phns, proms, langs = synth_batch(int(rng.integers(1 << 20)), B, n_phn=int(rng.integers(4, 20)),
+                                     n_prom=int(rng.integers(3, 30)), ragged=bool(rng.random() < 0.7))
+    lens = [int(rng.integers(3, 30)) for _ in range(B)]
+    lens = [l + 1 if l == 8 else l for l in lens]                       # (8 frames would read as training, ar_nar.py:927-931)
+    kw = dict(max_steps=int(rng.integers(2, 9)))
+    if rng.random() < 0.4:
+        kw["cfg_strength"] = float(rng.choice([1.0, 3.5]))
+    if rng.random() < 0.3:
+        kw["minimum_cfg_strength"] = float(rng.choice([0.0, 1.5]))
+    if rng.random() < 0.3:
+        kw["sampling_scores_masked_only"] = True
+    if rng.random() < 0.3:
+        kw["sampling_scores_remask"] = True
+    if rng.random() < 0.3:
+        kw["annealed_sampling"] = False
+    desc = f"seed {seed}: {kind} B={B} lens={lens} {kw}"
+    got = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, len_list=lens, temperature=0.0, **kw)
+    lvl0 = o.nar_masked(phns, proms, langs, lens, temperature=0.0, **kw)
+    want = o.nar(phns, proms, langs, lvl0, temperature=0.0, **({"cfg_strength": kw["cfg_strength"]} if "cfg_strength" in kw else {}))
+    bad = total = 0
+    for b in range(B):
+        g, w = got[b].cpu().numpy(), want[b].numpy()
+        assert g.shape == w.shape == (lens[b], 8), desc
+        bad += int((g != w).any(axis=1).sum())
+        total += lens[b]
+    assert bad <= max(1, total // 20), f"{desc}\n{bad} of {total} frames differ"
