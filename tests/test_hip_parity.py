@@ -165,6 +165,34 @@ def test_gemm_normed_vs_fp64_and_unfused(gpu_device, case):
         assert e_new < 1e-2 and e_new < 1.5 * e_old + 1e-4, (e_new, e_old)     # no further from the truth than the unfused path
 
 
+def test_gemm_normed_rope_tile_kernels_agree(gpu_device):
+    """The q/k/v projection with norm and RoPE in the epilogue runs on 256 x 192 ping-pong tiles at M = 12,176 and on the
+    128 x 128 kernel at M = 1,100: an output row depends on its own input row only and both kernels add the K-steps in the
+    same order, so the first 1,100 rows of the large call are bit-identical to the small call."""
+    from vall_e_amd import _lib as L
+    lib = L.load()
+    M, m, N, K = 12176, 1100, 3072, 1024
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(M, K, generator=g) * (0.5 + 2 * torch.rand(M, 1, generator=g))).bfloat16().to(gpu_device)
+    wf = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(gpu_device)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, 64, 2).float() / 64))
+    fr = torch.arange(1024).float()[:, None] * inv[None, :]
+    rope = torch.stack((fr.cos(), fr.sin()), dim=-1).contiguous().to(gpu_device)
+    pos = torch.randint(0, 1000, (M,), generator=g, dtype=torch.int32).to(gpu_device)
+    big = torch.zeros((M + 2, N), dtype=torch.bfloat16, device=gpu_device)
+    small = torch.zeros((m, N), dtype=torch.bfloat16, device=gpu_device)
+    L.check(lib.valle_gemm_normed(L.ptr(x), L.ptr(wf), L.ptr(big), M, N, K, N, 0, 1e-6, L.ptr(rope), L.ptr(pos), L.stream_ptr()))
+    L.check(lib.valle_gemm_normed(L.ptr(x), L.ptr(wf), L.ptr(small), m, N, K, N, 0, 1e-6, L.ptr(rope), L.ptr(pos), L.stream_ptr()))
+    assert (big[M:] == 0).all(), "rows behind M were written"
+    assert torch.equal(big[:m].view(torch.int16).cpu(), small.view(torch.int16).cpu())
+    # and the tail rows of the last (ragged) tile against fp64
+    rows = slice(M - 40, M)
+    xr = x[rows].double().cpu()
+    acc = (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6)) @ wf.double().cpu().T
+    v = big[rows, 2048:].double().cpu()                                              # the v part is not rotated
+    assert ((v - acc[:, 2048:]).norm() / acc[:, 2048:].norm()).item() < 1e-2
+
+
 def test_sampler_known_answers(gpu_device):
     """valle_sample / valle_cfg_combine against the reference's own sampler outputs (samplers_kat)."""
     m = hip_model("tiny")

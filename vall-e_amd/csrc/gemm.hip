@@ -23,7 +23,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[NI][MJ], int nw0, int
     if constexpr (EPI == GEMM_EPI_ROPE) {
         // QKV projection: q and k columns are pair-interleaved, a lane's 4 columns are two RoPE pairs
         // (arch/llama.py:48-61); same arithmetic as rope_kv_kernel: operands rounded to the storage type, the two
-        // products rounded separately.  rope_rows (LDS): the (cos, sin) row of each of the workgroup's 128 positions,
+        // products rounded separately.  rope_rows (LDS): the (cos, sin) rows of this wave's positions (its first m row first),
         // [row][68 floats], staged by the kernel -- a row serves every head, so it is fetched once per workgroup.
         T* C = (T*)Cout;
         typedef T vec4 __attribute__((ext_vector_type(4)));
@@ -33,7 +33,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[NI][MJ], int nw0, int
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < MJ; ++j)
-                rp[i][j] = *reinterpret_cast<const f32x4*>(rope_rows + ((mw0 & 127) + j * 16 + fr) * 68 + i * 16 + fq * 4);
+                rp[i][j] = *reinterpret_cast<const f32x4*>(rope_rows + (j * 16 + fr) * 68 + (i & 3) * 16 + fq * 4);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int nb = nw0 + i * 16 + fq * 4;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void gemm_glds_bf16_kernel(const bf16* __restr
             *reinterpret_cast<f32x4*>(rope_rows + (idx >> 4) * 68 + (idx & 15) * 4) = rrow[t];
         }
         __syncthreads();
-        gemm_epilogue<bf16, EPI>(acc, n0 + wn * 64, m0 + wm * 64, fr, fq, bias, resid, Cout, M, N, ldc, rope_rows);
+        gemm_epilogue<bf16, EPI>(acc, n0 + wn * 64, m0 + wm * 64, fr, fq, bias, resid, Cout, M, N, ldc, rope_rows + wm * 64 * 68);
     } else {
         gemm_epilogue<bf16, EPI>(acc, n0 + wn * 64, m0 + wm * 64, fr, fq, bias, resid, Cout, M, N, ldc);
     }
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
     const int grp = wave >> 2, wi = wave & 3;
     const int nh = wi & 1, mq = (wi >> 1) + 2 * grp;                       // n half (128 rows), m quarter (64 rows)
     const int fr = lane & 15, fq = lane >> 4;
-    static_assert(MQR == 64 || (MQR == 48 && !NORM), "m rows per wave");
+    static_assert(MQR == 64 || MQR == 48, "m rows per wave");
     constexpr int TMR = 4 * MQR, MJ = MQR / 16, PPW = (32 + TMR / 8) / 8;    // tile rows, 16-row m tiles per wave, pieces per wave
     const int n0 = blockIdx.x * 256, m0 = blockIdx.y * TMR;
 
@@ -477,7 +477,8 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
     auto sq_b = [&](int j, bf16x8 (&Bf)[2][2]) {                           // (issued in an MFMA slot, behind the MFMAs)
         if constexpr (NORM) {
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) ssq[j * 2 + ct] = ssq8(Bf[ct][1], ssq8(Bf[ct][0], ssq[j * 2 + ct]));
+            for (int ct = 0; ct < 2; ++ct)
+                if (j * 2 + ct < MJ) ssq[j * 2 + ct] = ssq8(Bf[ct][1], ssq8(Bf[ct][0], ssq[j * 2 + ct]));
         }
     };
     auto quad = [&](int i, int j, bf16x8 (&Bf)[2][2]) {
@@ -495,6 +496,21 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
 #define PP_END_READ()  do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 #define PP_END_MFMA()  __builtin_amdgcn_s_barrier()
 
+    // EPI_ROPE (q/k/v projection, bias = RoPE table, resid = positions): the (cos, sin) rows of the tile's positions are
+    // requested now (16 B pieces, TMR * 16 of them over 512 threads), live in registers through the main loop and reach the
+    // epilogue through LDS
+    constexpr int RPT = TMR * 16 / 512;
+    [[maybe_unused]] f32x4 rrow[RPT];
+    if constexpr (EPI == GEMM_EPI_ROPE) {
+        const int32_t* pos = reinterpret_cast<const int32_t*>(resid);
+        const float* tab = reinterpret_cast<const float*>(bias);
+#pragma unroll
+        for (int t = 0; t < RPT; ++t) {
+            const int idx = tid + 512 * t;                 // row = idx / 16, 16-byte piece = idx % 16
+            int m = m0 + (idx >> 4); m = m < M ? m : M - 1;
+            rrow[t] = *reinterpret_cast<const f32x4*>(tab + (size_t)pos[m] * 64 + (idx & 15) * 4);
+        }
+    }
     const int nt = K / 64;
     stage(0, 0);
     if (nt > 1) stage(1, 1);
@@ -533,13 +549,25 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
 #undef PP_END_MFMA
     if constexpr (NORM) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < MJ; ++j) {
             const float rinv = row_rinv(ssq[j], K, eps);
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i][j] *= rinv;
         }
     }
-    gemm_epilogue<bf16, EPI, 8, MJ>(acc, n0 + nh * 128, m0 + mq * MQR, fr, fq, bias, resid, Cout, M, N, ldc);
+    if constexpr (EPI == GEMM_EPI_ROPE) {
+        float* rope_rows = reinterpret_cast<float*>(lds);                  // TMR x 68 floats (<= 70 KB of the 128 KB)
+        __syncthreads();                                                   // the last tile has been read by every wave
+#pragma unroll
+        for (int t = 0; t < RPT; ++t) {
+            const int idx = tid + 512 * t;
+            *reinterpret_cast<f32x4*>(rope_rows + (idx >> 4) * 68 + (idx & 15) * 4) = rrow[t];
+        }
+        __syncthreads();
+        gemm_epilogue<bf16, EPI, 8, MJ>(acc, n0 + nh * 128, m0 + mq * MQR, fr, fq, bias, resid, Cout, M, N, ldc, rope_rows + mq * MQR * 68);
+    } else {
+        gemm_epilogue<bf16, EPI, 8, MJ>(acc, n0 + nh * 128, m0 + mq * MQR, fr, fq, bias, resid, Cout, M, N, ldc);
+    }
 }
 
 static int gemm_glds_dispatch(const void* A, const void* W, const void* bias, const void* resid, void* C,
@@ -618,7 +646,18 @@ extern "C" int valle_gemm_normed(const void* A, const void* Wf, void* C, int M, 
     } else {
         dim3 grid(ceil_div(N, 128), ceil_div(M, 128));
         if (epilogue == VALLE_EPI_GEGLU) gemm_glds_bf16_kernel<VALLE_EPI_GEGLU, true><<<grid, 256, 0, s>>>(X, W, nullptr, nullptr, C, M, N, K, ldc, eps);
-        else if (rope) gemm_glds_bf16_kernel<GEMM_EPI_ROPE, true><<<grid, 256, 0, s>>>(X, W, rope, (const bf16*)pos, C, M, N, K, ldc, eps);
+        else if (rope) {
+            // 256 x 192 ping-pong tiles where they make (nearly) whole rounds of 256 workgroups (M = 12,176, d = 1,024:
+            // 12 x 64 = 3.0 rounds, 95 vs 105 us without the epilogue); else the 128 x 128 kernel
+            const float rounds = N % 256 == 0 ? (float)(N / 256) * (float)ceil_div(M, 192) / 256.f : 0.f;
+            const float frac = rounds - (float)(int)rounds;
+            if (rounds >= 2.f && (frac == 0.f || frac > 0.7f)) {
+                dim3 g192(N / 256, ceil_div(M, 192));
+                gemm_pp256_bf16_kernel<GEMM_EPI_ROPE, true, 48><<<g192, 512, 0, s>>>(X, W, rope, (const bf16*)pos, C, M, N, K, ldc, eps);
+            } else {
+                gemm_glds_bf16_kernel<GEMM_EPI_ROPE, true><<<grid, 256, 0, s>>>(X, W, rope, (const bf16*)pos, C, M, N, K, ldc, eps);
+            }
+        }
         else gemm_glds_bf16_kernel<VALLE_EPI_STORE, true><<<grid, 256, 0, s>>>(X, W, nullptr, nullptr, C, M, N, K, ldc, eps);
     }
     VALLE_LAUNCH_CHECK();
