@@ -38,7 +38,7 @@ def _first_diff(a, b):
     return n if len(a) != len(b) else -1
 
 
-@pytest.mark.parametrize("seed", list(range(48)))
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("VALLE_FUZZ_SEEDS", "48")))))
 def test_random_option_mix_matches_oracle(gpu_device, seed):
     from vall_e_amd.synth import synth_batch
     rng = np.random.default_rng(1000 + seed)
@@ -88,8 +88,9 @@ def test_random_option_mix_matches_oracle(gpu_device, seed):
     idx = [b for b in usable if len(want[b]) > 0]
     if not idx or kw.get("input_prompt_prefix"):
         return
-    if len(want[idx[0]]) == 8:                # reference quirk: a level-0 response of exactly n_resp_levels frames reads as
-        return                                # "all levels present" = training (ar_nar.py:927-931); both sides refuse it
+    if next(iter({len(want[b]) for b in idx})) == 8:   # reference quirk (ar_nar.py:927-931): when the element the reference
+        return                                         # takes from the SET of last dimensions is n_resp_levels -- a level-0
+                                                       # response of exactly 8 frames -- the call reads as training; both sides refuse
     nar_kw = {"cfg_strength": kw["cfg_strength"]} if "cfg_strength" in kw and rng.random() < 0.5 else {}
     sub = lambda l: [l[b] for b in idx]
     full = m(task_list=["tts"] * len(idx), phns_list=sub(phns), proms_list=sub(proms), lang_list=sub(langs),
@@ -105,7 +106,7 @@ def test_random_option_mix_matches_oracle(gpu_device, seed):
     assert bad <= max(1, total // 50), f"{desc}\n{bad} of {total} NAR rows differ"
 
 
-@pytest.mark.parametrize("seed", list(range(16)))
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("VALLE_FUZZ_SEEDS", "48")) // 3)))
 def test_random_narlen_mix_matches_oracle(gpu_device, seed):
     """NAR-len demasking (level 0 by iterative demasking, then the NAR levels) under random lengths, step counts, guidance
     floors and score options, causal and non-causal models.  Demasking decisions are lowest-k cuts over scores: a single
