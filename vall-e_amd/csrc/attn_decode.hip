@@ -66,7 +66,6 @@ __device__ __forceinline__ void attn_dec_issue(const bf16* kb, const bf16* vb, i
 template <int MAXC, int NW>
 __device__ __forceinline__ void attn_dec_consume(int p0, int wave, int g, int n_keys, const u32x4& qb,
                                                  u32x4 (&kk)[MAXC], u32x4 (&vv)[MAXC], float& m, float& l, float (&o)[8]) {
-    static_assert(MAXC % 2 == 0, "chunks are consumed in pairs");
     float s[MAXC];
     float mloc = -INFINITY;
 #pragma unroll
@@ -94,12 +93,15 @@ __device__ __forceinline__ void attn_dec_consume(int p0, int wave, int g, int n_
         for (int e = 0; e < 8; ++e) o[e] *= alpha;
 #pragma unroll
         for (int c = 0; c < MAXC; c += 2) {
-            const float pa = __builtin_amdgcn_exp2f(s[c] - mn), pb = __builtin_amdgcn_exp2f(s[c + 1] - mn);   // masked keys: 0
+            // (an odd chunk count pairs its last chunk with an empty one: the same arithmetic as a masked chunk)
+            const bool pair = c + 1 < MAXC;
+            const int c1 = pair ? c + 1 : c;
+            const float pa = __builtin_amdgcn_exp2f(s[c] - mn), pb = pair ? __builtin_amdgcn_exp2f(s[c1] - mn) : 0.f;   // masked keys: 0
             l += pa + pb;
             const bf16x2_t pp = {(bf16)pa, (bf16)pb};
             const uint32_t ppu = __builtin_bit_cast(uint32_t, pp);
             const uint32_t va[4] = {vv[c].x, vv[c].y, vv[c].z, vv[c].w};
-            const uint32_t vb2[4] = {vv[c + 1].x, vv[c + 1].y, vv[c + 1].z, vv[c + 1].w};
+            const uint32_t vb2[4] = {pair ? vv[c1].x : 0u, pair ? vv[c1].y : 0u, pair ? vv[c1].z : 0u, pair ? vv[c1].w : 0u};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t lo = __builtin_amdgcn_perm(vb2[i], va[i], 0x05040100u);   // (v_c[2i],   v_c+1[2i])
@@ -110,6 +112,23 @@ __device__ __forceinline__ void attn_dec_consume(int p0, int wave, int g, int n_
         }
         m = mn;
     }
+}
+
+__device__ __forceinline__ void attn_dec_scale_q(u32x4& qb) {      // q * 1/sqrt(64): exact in bf16
+    bf16x8 qv = __builtin_bit_cast(bf16x8, qb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = (bf16)((float)qv[e] * 0.125f);
+    qb = __builtin_bit_cast(u32x4, qv);
+}
+
+// the whole context in one pass of MC chunks per wave (n_keys <= MC x NW x 8)
+template <int MC, int NW>
+__device__ __forceinline__ void attn_dec_single(const bf16* kb, const bf16* vb, int wave, int g, int n_keys, u32x4 qb,
+                                                float& m, float& l, float (&o)[8]) {
+    u32x4 kk[MC], vv[MC];
+    attn_dec_issue<MC, NW>(kb, vb, 0, wave, g, n_keys, kk, vv);
+    attn_dec_scale_q(qb);
+    attn_dec_consume<MC, NW>(0, wave, g, n_keys, qb, kk, vv, m, l, o);
 }
 
 template <int MAXC, int NW>
@@ -139,19 +158,36 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(const bf16* _
     const size_t base = ((size_t)sl * H + h) * cache_T * 64 + sub * 8;
     const bf16* kb = pK + base;
     const bf16* vb = pV + base;
-    u32x4 kA[MAXC], vA[MAXC], kB[MAXC], vB[MAXC];
-    attn_dec_issue<MAXC, NW>(kb, vb, 0, wave, g, bound, kA, vA);
-    {   // q * 1/sqrt(64): exact in bf16
-        bf16x8 qv = __builtin_bit_cast(bf16x8, qb);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qv[e] = (bf16)((float)qv[e] * 0.125f);
-        qb = __builtin_bit_cast(u32x4, qv);
-    }
     float m = -INFINITY, l = 0.f, o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    // A context that fits one pass of fewer chunks takes a straight-line body of exactly that many (a pass of MAXC chunks
+    // requests and scores MAXC x NW x 8 keys whatever the context: at 311..761 keys of 768 up to 60 % of that was padding).
+    // The choice is uniform over the workgroup; every body is branch-free, so loads are still consumed as they land.
+#ifndef ATTN_DEC_NO_SHORT     // (dev: the one-size body alone, for the comparison in profiles/README.md)
+    if constexpr (MAXC == 12) {
+        switch ((bound + NW * 8 - 1) / (NW * 8)) {          // chunks per wave the context needs
+            case 0: case 1: case 2: case 3: case 4: attn_dec_single<4, NW>(kb, vb, wave, g, n_keys, qb, m, l, o); break;
+            case 5: case 6: attn_dec_single<6, NW>(kb, vb, wave, g, n_keys, qb, m, l, o); break;
+            case 7: attn_dec_single<7, NW>(kb, vb, wave, g, n_keys, qb, m, l, o); break;
+            case 8: attn_dec_single<8, NW>(kb, vb, wave, g, n_keys, qb, m, l, o); break;
+            case 9: attn_dec_single<9, NW>(kb, vb, wave, g, n_keys, qb, m, l, o); break;
+            case 10: attn_dec_single<10, NW>(kb, vb, wave, g, n_keys, qb, m, l, o); break;
+            case 11: attn_dec_single<11, NW>(kb, vb, wave, g, n_keys, qb, m, l, o); break;
+            default: break;
+        }
+    }
+    const bool general = MAXC != 12 || bound > NW * 8 * 11;
+#else
+    const bool general = true;
+#endif
+    u32x4 kA[MAXC], vA[MAXC], kB[MAXC], vB[MAXC];
+    if (general) {
+    attn_dec_issue<MAXC, NW>(kb, vb, 0, wave, g, bound, kA, vA);
+    attn_dec_scale_q(qb);
+    }
 
-    for (int p0 = 0; p0 < bound; p0 += 2 * PK) {
+    for (int p0 = 0; general && p0 < bound; p0 += 2 * PK) {
         const bool more = p0 + PK < bound;                                  // wave-uniform
         if (more) attn_dec_issue<MAXC, NW>(kb, vb, p0 + PK, wave, g, bound, kB, vB);
 #ifdef VALLE_STAMPS
