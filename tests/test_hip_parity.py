@@ -1028,11 +1028,14 @@ def test_narlen_b64_properties(gpu_device):
     assert agree > 0.9, agree          # bf16 GEMM tiles see different neighbours; greedy near-ties may flip a few codes
 
 
-@pytest.mark.parametrize("cache_T,ctx", [(96, [1, 7, 96]), (512, [512, 65, 300]), (1024, [1000, 3, 769, 768]), (2600, [2561, 1537, 40])])
+@pytest.mark.parametrize("cache_T,ctx", [(96, [1, 7, 96]), (512, [512, 65, 300]), (1024, [1000, 3, 769, 768]), (2600, [2561, 1537, 40]),
+                                         (800, [255, 256, 257, 320, 321, 384, 385]), (800, [447, 448, 449, 512, 513, 576, 577]),
+                                         (800, [639, 640, 641, 703, 704, 705, 767])])
 def test_attn_decode_bf16_vs_fp64(gpu_device, cache_T, ctx):
     """valle_attn_decode (bf16 KV-cache attention, one query per utterance and head) against an fp64
     softmax(q.K^T/8) V over the first ctx_b rows of each utterance's slot: ragged contexts, single- and
-    multi-pass key ranges, waves without keys, a permuted slot table; garbage beyond ctx_b must not leak."""
+    multi-pass key ranges (every chunk-count body of the one-pass form and its boundaries), waves without keys,
+    a permuted slot table; garbage beyond ctx_b must not leak."""
     from vall_e_amd import _lib as L
     B, H, Dh = len(ctx), 4, 64
     d = H * Dh
