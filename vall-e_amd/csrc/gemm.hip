@@ -572,9 +572,10 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
 
 static int gemm_glds_dispatch(const void* A, const void* W, const void* bias, const void* resid, void* C,
                               int M, int N, int K, int ldc, int epi, hipStream_t s) {
-    // down_proj (K = d_ff >= 2048, narrow N): 64 K-tiles amortise the 256^2 ping-pong kernel's fill and epilogue even
-    // though N = 1024 gives only 4 x ceil(M/256) workgroups (measured 113.6 vs 133.5 us at M = 12,176)
-    if (epi == VALLE_EPI_RESID && K >= 2048 && M >= 2048 && N >= 256) {
+    // down_proj (K = d_ff, narrow N): 64 K-tiles amortise the 256^2 ping-pong kernel's fill and epilogue even
+    // though N = 1024 gives only 4 x ceil(M/256) workgroups (measured 113.6 vs 133.5 us at M = 12,176); o_proj (K = 1,024)
+    // gains too once the 192-row tiles fill the chip in one round (43.1 vs 47.1 us for the 64 x 128 kernel, tools/micro_gemm)
+    if (epi == VALLE_EPI_RESID && K >= 1024 && M >= 2048 && N >= 256) {
         // one workgroup per CU: what counts is the number of rounds of 256 workgroups.  192-row tiles do 3/4 of the MFMA work
         // of a 256-row tile in ~0.85 of its time; they win where they save a round or fill idle CUs (M = 12,176, N = 1,024:
         // 192 workgroups of 256 rows leave 64 CUs idle, 256 workgroups of 192 rows fill the chip)
