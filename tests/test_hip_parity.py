@@ -1064,6 +1064,28 @@ def test_attn_decode_bf16_vs_fp64(gpu_device, cache_T, ctx):
     assert ((got - want).norm() / want.norm()).item() < 1e-2
 
 
+def test_attn_decode_empty_context_reads_nothing_out_of_bounds(gpu_device):
+    """An utterance with no key at all (ctx_len 0 through the operator entry point): softmax over nothing is 0/0 = nan, as in
+    torch; its neighbours are unaffected and no row in front of the cache is touched."""
+    from vall_e_amd import _lib as L
+    B, H, Dh, cache_T = 3, 4, 64, 64
+    d = H * Dh
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B, 3 * d, generator=g).bfloat16().to(gpu_device)
+    kc = torch.randn(B, H, cache_T, Dh, generator=g).bfloat16().to(gpu_device)
+    vc = torch.randn(B, H, cache_T, Dh, generator=g).bfloat16().to(gpu_device)
+    cl = torch.tensor([0, 9, 0], dtype=torch.int32, device=gpu_device)
+    out = torch.zeros(B, d, dtype=torch.bfloat16, device=gpu_device)
+    L.check(L.load().valle_attn_decode(L.ptr(qkv), L.ptr(kc), L.ptr(vc), L.ptr(cl), None, L.ptr(out), B, H, Dh, cache_T,
+                                       L.BF16, L.stream_ptr()))
+    got = out.float().cpu()
+    assert torch.isnan(got[0]).all() and torch.isnan(got[2]).all()
+    q = qkv[1, :d].double().view(H, 1, Dh).cpu()
+    p = torch.softmax(q @ kc[1, :, :9].double().cpu().transpose(1, 2) / 8.0, dim=-1)
+    want = (p @ vc[1, :, :9].double().cpu()).reshape(d)
+    assert ((got[1].double() - want).norm() / want.norm()).item() < 1e-2
+
+
 def test_reference_surface_inputs_forward_super_sample(gpu_device):
     """The lower-level surface other reference code uses (ar_nar.py:36-37, base.py:560, :1280):
     model.inputs(...) -> model.forward_super(inputs) -> model.sample(logits, ...) gives the same logits as the

@@ -51,13 +51,13 @@ __device__ __forceinline__ void attn_dec_issue(const bf16* kb, const bf16* vb, i
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         int key = p0 + (c * NW + wave) * 8 + g;
-        key = key < bound ? key : bound - 1;
+        key = key < bound ? key : (bound > 0 ? bound - 1 : 0);    // (an empty context reads row 0 and masks it)
         kk[c] = LOAD_KV(reinterpret_cast<const u32x4*>(kb + (size_t)key * 64));
     }
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         int key = p0 + (c * NW + wave) * 8 + g;
-        key = key < bound ? key : bound - 1;
+        key = key < bound ? key : (bound > 0 ? bound - 1 : 0);
         vv[c] = LOAD_KV(reinterpret_cast<const u32x4*>(vb + (size_t)key * 64));
     }
 }
