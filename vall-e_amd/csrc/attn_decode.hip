@@ -152,7 +152,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_bf16_kernel(const bf16* _
     const int ctx = pCtx[b];
     if (ctx < 0) return;        // finished utterance (valle_ar_state.early_exit stores ~ctx_len): the whole workgroup leaves
                                 // before any barrier, its K/V rows stay in HBM, its output row keeps its last value
-    const int n_keys = ctx + a.ctx_extra;
+    const int n_keys = min(ctx + a.ctx_extra, cache_T);      // (a length beyond the cache rows is the caller's error; never read past them)
     const int bound = n_keys;   // (a host bound on the batch's longest context, so that the loads need not wait for ctx_len[b],
                                 // measured no faster: 8.74 vs 8.70 us)
     const size_t base = ((size_t)sl * H + h) * cache_T * 64 + sub * 8;
