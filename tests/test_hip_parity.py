@@ -876,6 +876,28 @@ def test_bf16_decode_batch_sizes_vs_oracle(gpu_device, B):
         assert rel_l2(logits[step], want) < 4e-2, step
 
 
+def test_full_width_decode_above_16_utterances_vs_oracle(gpu_device):
+    """The decode forms of 17-32 utterances at full width (dec_wave_kernel<.., 16, 1, true, 2, 1>: K = d_model on one wave, two
+    utterance tiles; <1, 2, 2 / 8, false, 2, 4>; attn_decode_bf16_kernel<6, 8>), which the bench shape (16 utterances) does not
+    take and BASELINE configs[4] (32 utterances) does: full model, bf16, 24 ragged utterances, per-step logits of the KV-cache
+    decode, teacher-forced on the HIP path's own codes, against the bf16 oracle: rel-L2 <= 4e-2 per step."""
+    from vall_e_amd.synth import synth_batch
+    import valle_oracle as vo
+    B = 24
+    phns, proms, langs = synth_batch(4242, B, n_phn=14, n_prom=24, ragged=True)
+    m = hip_model("full", torch.bfloat16, stop_bias=-30000.0)
+    codes, logits = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=8,
+                      temperature=0.0, return_logits=True, step_chunk=4)
+    o = oracle("full", torch.bfloat16, stop_bias=-30000.0)
+    for step in (0, 4, 7):
+        plans = [vo.plan_sequence(phns[i], langs[i], proms[i], codes[i][:step].cpu(), 0) for i in range(B)]
+        want = torch.stack([l[0].float() for l in o.forward(plans, rows=[1] * B)])[:, :1024]
+        got = logits[step][:, :1024].float().cpu()
+        assert rel_l2(got, want) < 4e-2, (step, rel_l2(got, want))
+        worst = max(rel_l2(got[b], want[b]) for b in range(B))
+        assert worst < 8e-2, (step, worst)
+
+
 @pytest.mark.parametrize("kind,B", [("half2", 5), ("half2", 20), ("s075_2", 5), ("s075_2", 20)])
 def test_other_model_sizes_vs_oracle(gpu_device, kind, B):
     """The reference's other width presets (config.py:462-490: "half" = 512 / 8 heads, 0.75 = 768 / 12 heads; two layers
@@ -1036,8 +1058,19 @@ def test_attn_decode_bf16_vs_fp64(gpu_device, cache_T, ctx):
     softmax(q.K^T/8) V over the first ctx_b rows of each utterance's slot: ragged contexts, single- and
     multi-pass key ranges (every chunk-count body of the one-pass form and its boundaries), waves without keys,
     a permuted slot table; garbage beyond ctx_b must not leak."""
+    _attn_decode_case(gpu_device, cache_T, ctx, 4)
+
+
+def test_attn_decode_bf16_above_256_workgroups_vs_fp64(gpu_device):
+    """The same check on the form taken above 256 (utterance, head) pairs (attn_decode_bf16_kernel<6, 8>: 6-chunk passes, two
+    workgroups per CU; 17-32 utterances of 16 heads, BASELINE configs[4]): 18 utterances x 16 heads, contexts on both sides
+    of the pass boundaries (384 keys per pass) and up to four passes."""
+    _attn_decode_case(gpu_device, 1536, [1, 63, 64, 383, 384, 385, 500, 767, 768, 769, 1000, 1151, 1152, 1153, 1500, 1536, 7, 300], 16)
+
+
+def _attn_decode_case(gpu_device, cache_T, ctx, H):
     from vall_e_amd import _lib as L
-    B, H, Dh = len(ctx), 4, 64
+    B, Dh = len(ctx), 64
     d = H * Dh
     g = torch.Generator().manual_seed(cache_T + B)
     qkv = torch.randn(B, 3 * d, generator=g).bfloat16()
