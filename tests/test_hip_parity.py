@@ -193,6 +193,35 @@ def test_gemm_normed_rope_tile_kernels_agree(gpu_device):
     assert ((v - acc[:, 2048:]).norm() / acc[:, 2048:].norm()).item() < 1e-2
 
 
+def test_gemm_normed_geglu_tile_kernels_agree(gpu_device):
+    """The gate/up projection with the folded norm and the GEGLU epilogue runs on the 256 x 256 ping-pong kernel (32x32x16 MFMAs)
+    from 1,024 rows on and on the 128 x 128 kernel (16x16x32 MFMAs) below: both add the K-steps and the squares of a row in the
+    same order, so the first 900 rows of a 2,500-row call are bit-identical to a 900-row call -- an utterance alone and the same
+    utterance inside a batch get the same activations.  The un-normed wide GEMM (valle_gemm, plain store) likewise."""
+    from vall_e_amd import _lib as L
+    lib = L.load()
+    bf = L.dtype_code(torch.bfloat16)
+    M, m, N, K = 2500, 900, 8192, 1024
+    g = torch.Generator().manual_seed(6)
+    x = (torch.randn(M, K, generator=g) * (0.5 + 2 * torch.rand(M, 1, generator=g))).bfloat16().to(gpu_device)
+    wf = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(gpu_device)
+    big = torch.zeros((M + 2, N // 2), dtype=torch.bfloat16, device=gpu_device)
+    small = torch.zeros((m, N // 2), dtype=torch.bfloat16, device=gpu_device)
+    L.check(lib.valle_gemm_normed(L.ptr(x), L.ptr(wf), L.ptr(big), M, N, K, N // 2, 2, 1e-6, None, None, L.stream_ptr()))
+    L.check(lib.valle_gemm_normed(L.ptr(x), L.ptr(wf), L.ptr(small), m, N, K, N // 2, 2, 1e-6, None, None, L.stream_ptr()))
+    assert (big[M:] == 0).all(), "rows behind M were written"
+    assert torch.equal(big[:m].view(torch.int16).cpu(), small.view(torch.int16).cpu())
+    big2 = torch.zeros((M + 2, N), dtype=torch.bfloat16, device=gpu_device)
+    small2 = torch.zeros((m, N), dtype=torch.bfloat16, device=gpu_device)
+    L.check(lib.valle_gemm(L.ptr(x), L.ptr(wf), None, None, L.ptr(big2), M, N, K, N, 0, bf, L.stream_ptr()))
+    L.check(lib.valle_gemm(L.ptr(x), L.ptr(wf), None, None, L.ptr(small2), m, N, K, N, 0, bf, L.stream_ptr()))
+    assert (big2[M:] == 0).all(), "rows behind M were written"
+    assert torch.equal(big2[:m].view(torch.int16).cpu(), small2.view(torch.int16).cpu())
+    rows = slice(M - 40, M)                                  # the tail rows of the last (ragged) tile against fp64
+    want = x[rows].double().cpu() @ wf.double().cpu().T
+    assert ((big2[rows].double().cpu() - want).norm() / want.norm()).item() < 1e-2
+
+
 def test_sampler_known_answers(gpu_device):
     """valle_sample / valle_cfg_combine against the reference's own sampler outputs (samplers_kat)."""
     m = hip_model("tiny")
