@@ -537,6 +537,87 @@ def test_bench_shape_b16_bf16_vs_oracle(gpu_device, ragged):
         assert worst < 8e-2, (step, worst)
 
 
+@pytest.mark.parametrize("q", [1, 7])
+def test_bench_shape_nar_level_b16_bf16_vs_oracle(gpu_device, q):
+    """One NAR level of BASELINE.json configs[1] at its own shape, end to end: full model, bf16, the bench's
+    synthetic batch (16 x (80 phonemes + 225 prompt frames + 450 response frames) = 12,176 packed rows, 7,200 requested
+    rows) through the very call forward_nar makes -- the only shape at which the dense pass takes
+    gemm_pp256_bf16_kernel<5, true, 48> (q/k/v + norm + RoPE), <1, false, 48> (o_proj, down_proj) and <2, true, 64>
+    (gate/up + norm + GEGLU) together, plus the last layer on the requested rows alone.  Input codes: the HIP path's own AR
+    and NAR results.  Response-row logits against the bf16 oracle (the reference's bf16 semantics): rel-L2 <= 4e-2 over the
+    batch, <= 8e-2 per utterance; and the level's greedy codes agree with the oracle's on >= 90 % of the frames (random
+    weights make many near ties at bf16 resolution; a wrong tile would give chance level, ~0.1 %)."""
+    from vall_e_amd.synth import synth_batch
+    import valle_oracle as vo
+    B, R = 16, 450
+    phns, proms, langs = synth_batch(1234, B, n_phn=80, n_prom=225)
+    m = hip_model("full", torch.bfloat16, stop_bias=-30000.0)
+    kw = dict(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs)
+    codes = m(max_duration=R, temperature=0.0, step_chunk=R, **kw)
+    assert all(c.shape[0] == R for c in codes)
+    full = m(resps_list=[c.clone() for c in codes], temperature=0.0, **kw)
+    assert all(tuple(f.shape) == (R, 8) for f in full)
+    known = [f[:, :q].cpu() for f in full]
+    plan = m.plan(phns, langs, proms, known, q)
+    assert plan.M == 16 * 761
+    rows, off = m.tail_rows(plan, [R] * B)
+    got = m.forward_dense(plan, rows)[:, :1024].float().cpu()
+    o = oracle("full", torch.bfloat16, stop_bias=-30000.0)
+    want = torch.cat([l.float() for l in o.forward([vo.plan_sequence(phns[i], langs[i], proms[i], known[i], q) for i in range(B)],
+                                                   rows=[R] * B)])[:, :1024]
+    assert rel_l2(got, want) < 4e-2, rel_l2(got, want)
+    worst = max(rel_l2(got[off[b]:off[b + 1]], want[off[b]:off[b + 1]]) for b in range(B))
+    assert worst < 8e-2, worst
+    agree = (got.argmax(-1) == want.argmax(-1)).float().mean().item()
+    print(f"NAR level {q} at 16 x 761: rel-L2 {rel_l2(got, want):.3e}, worst utterance {worst:.3e}, argmax agreement {agree:.4f}")
+    assert agree > 0.9, agree
+    same = torch.cat([f[:, q].cpu() for f in full])                     # the level forward_nar sampled from the same pass
+    assert (got.argmax(-1) == same).float().mean().item() > 0.999
+
+
+def test_bf16_lora_small_delta_vs_oracle(gpu_device):
+    """LoRA in bf16: the HIP path merges W + (alpha / rank) B A and rounds ONCE to bf16, the reference's default
+    (unmerged) bf16 forward keeps x A^T B^T as a separate low-rank term (models/lora.py:69-75).  With a realistic small
+    delta (|dW| ~ 2^-7 |W|, below one bf16 ulp of many weights) the two differ by roundings only: AR logits of the full
+    model against the bf16 oracle with the LoRA applied the reference's way stay inside the bf16 tolerance class of the
+    model without a LoRA, and the LoRA's effect on the logits is visible above that error."""
+    from vall_e_amd.synth import synth_batch
+    import valle_oracle as vo
+    cfg = model_cfg("full")
+    g = torch.Generator().manual_seed(11)
+    rank, alpha = 8, 8
+    lora = {}
+    sd = synth_weights("full")
+    for l in range(cfg.layers):
+        for name in ("self_attn.q_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj"):
+            W = sd[f"model.layers.{l}.{name}.weight"]
+            scale = float(W.std()) * 2.0 ** -7
+            lora[f"model.layers.{l}.{name}.lora_A"] = torch.randn(rank, W.shape[1], generator=g) / W.shape[1] ** 0.5
+            lora[f"model.layers.{l}.{name}.lora_B"] = torch.randn(W.shape[0], rank, generator=g) * scale * W.shape[1] ** 0.5 / rank ** 0.5
+    B = 3
+    phns, proms, langs = synth_batch(5, B, n_phn=30, n_prom=60, ragged=True)
+    resp = [torch.randint(0, 1024, (20 + 3 * i,), generator=g) for i in range(B)]
+    m = hip_model("full", torch.bfloat16)
+    m.load_lora(lora, rank=rank, alpha=alpha)
+    inp = dict(phns_list=phns, lang_list=langs, proms_list=proms, resps_list=resp)
+    m._call_state.lora_on = True
+    got = [l.float().cpu() for l in m.forward_super(inp, quant_levels=[0] * B).logits]
+    m._call_state.lora_on = False
+    base = [l.float().cpu() for l in m.forward_super(inp, quant_levels=[0] * B).logits]
+    o = oracle("full", torch.bfloat16)
+    plans = [vo.plan_sequence(phns[i], langs[i], proms[i], resp[i], 0) for i in range(B)]
+    want_base = [l.float() for l in o.forward(plans)]
+    o.load_lora(lora, rank, alpha)
+    o.set_lora_level(0)
+    want = [l.float() for l in o.forward(plans)]
+    e_base = max(rel_l2(a, b) for a, b in zip(base, want_base))
+    e_lora = max(rel_l2(a, b) for a, b in zip(got, want))
+    effect = max(rel_l2(a, b) for a, b in zip(want, want_base))
+    print(f"bf16 LoRA: error without {e_base:.3e}, with {e_lora:.3e}; the LoRA moves the logits by {effect:.3e}")
+    assert e_lora < 4e-2 and e_lora < 1.5 * e_base + 5e-3, (e_lora, e_base)
+    assert effect > 1e-3                                   # the adapter is not a no-op at this scale
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_early_exit_of_finished_utterances(gpu_device, dtype):
     """valle_ar_state.early_exit (the reference's own to-do, docs/README.md:85; loop at ar_nar.py:837-848): utterances that
@@ -1057,16 +1138,41 @@ def test_longform_b32_sampling_properties(gpu_device):
     assert rel_l2(lg[R - 1], want) < 4e-2
 
 
-def test_narlen_b64_properties(gpu_device):
-    """BASELINE configs[2] at full batch (64 utterances, NAR-len demasking + 7 NAR levels, cfg 2.5/0.75),
-    reduced to 6 demasking steps of 150 frames: no mask token survives, codes are in range, the run is
-    reproducible, and utterance i of the batch equals the same utterance run alone (batch independence:
-    the packed layout must not leak across utterances)."""
+def test_narlen_full_length_fp32_vs_oracle(gpu_device):
+    """BASELINE configs[2] at its own length: 450 frames x 25 demasking steps, guidance 2.5 / 0.75, then
+    the 7 NAR levels -- 2 utterances of the full model in fp32 against oracle.nar_masked + oracle.nar (reference
+    models/ar_nar.py:233-464, :466-586).  Demasking decisions are lowest-k cuts over scores, a near tie moves a position to
+    another step: agreement is asked of >= 95 % of the frames (the bar of the randomised NAR-len test)."""
     from vall_e_amd.synth import synth_batch
-    B, R = 64, 150
+    B, R = 2, 450
+    phns, proms, langs = synth_batch(99, B, n_phn=80, n_prom=225)
+    m = hip_model("full")
+    kw = dict(max_steps=25, temperature=0.0, cfg_strength=2.5, cfg_rescale=0.75)
+    got = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, len_list=[R] * B, **kw)
+    o = oracle("full")
+    lvl0 = o.nar_masked(phns, proms, langs, [R] * B, **kw)
+    want = o.nar(phns, proms, langs, lvl0, temperature=0.0, cfg_strength=2.5)
+    bad0 = bad = 0
+    for b in range(B):
+        g, w = got[b].cpu().numpy(), want[b].numpy()
+        assert g.shape == w.shape == (R, 8)
+        bad0 += int((g[:, 0] != w[:, 0]).sum())
+        bad += int((g != w).any(axis=1).sum())
+    print(f"NAR-len 2 x 450 frames x 25 steps fp32: {bad0} level-0 frames, {bad} frames (any level) of {B * R} differ from the oracle")
+    assert bad <= B * R // 20, (bad0, bad)
+
+
+def test_narlen_b64_properties(gpu_device):
+    """BASELINE configs[2] at full size: 64 ragged utterances, 450 frames, 25 demasking steps + 7 NAR levels, guidance
+    2.5 / 0.75, bf16 -- what tools/time_configs.py times.  No mask token survives, codes are in range, the run is
+    reproducible, and utterance i of the batch equals the same utterance run alone (batch independence: the packed layout
+    must not leak across utterances).  The solo run's GEMMs take other tiles (M = 761 against ~48,000 rows) and 25 rounds
+    of score cuts amplify bf16 near ties: measured agreement 0.97-1.0 per level-0 frame; asked: >= 0.93 (chance: 0.001)."""
+    from vall_e_amd.synth import synth_batch
+    B, R = 64, 450
     phns, proms, langs = synth_batch(99, B, n_phn=80, n_prom=225, ragged=True)
     m = hip_model("full", torch.bfloat16)
-    kw = dict(max_steps=6, temperature=0.0, cfg_strength=2.5, cfg_rescale=0.75)
+    kw = dict(max_steps=25, temperature=0.0, cfg_strength=2.5, cfg_rescale=0.75)
     out = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, len_list=[R] * B, **kw)
     assert len(out) == B
     for r in out:
@@ -1074,9 +1180,12 @@ def test_narlen_b64_properties(gpu_device):
     again = m(task_list=["tts"] * B, phns_list=phns, proms_list=proms, lang_list=langs, len_list=[R] * B, **kw)
     for a, b in zip(out, again):
         assert torch.equal(a, b)
-    solo = m(task_list=["tts"], phns_list=phns[5:6], proms_list=proms[5:6], lang_list=langs[5:6], len_list=[R], **kw)
-    agree = (solo[0] == out[5]).float().mean().item()
-    assert agree > 0.9, agree          # bf16 GEMM tiles see different neighbours; greedy near-ties may flip a few codes
+    agree = []
+    for i in (5, 40):
+        solo = m(task_list=["tts"], phns_list=phns[i:i + 1], proms_list=proms[i:i + 1], lang_list=langs[i:i + 1], len_list=[R], **kw)
+        agree.append((solo[0][:, 0] == out[i][:, 0]).float().mean().item())
+    print(f"NAR-len B=64 x 450 x 25 bf16: level-0 agreement of utterances 5 / 40 with their solo runs {agree}")
+    assert min(agree) > 0.93, agree
 
 
 @pytest.mark.parametrize("cache_T,ctx", [(96, [1, 7, 96]), (512, [512, 65, 300]), (1024, [1000, 3, 769, 768]), (2600, [2561, 1537, 40]),

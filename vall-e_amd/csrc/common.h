@@ -77,6 +77,7 @@ struct valle_model {
     const float** head_b;
     const void** head_pn;
     int32_t* head_n;
+    int device;                 // the GPU that was current in valle_model_create (-1: none)
 };
 
 struct SampleArgs {

@@ -10,6 +10,29 @@ extern "C" int valle_attn_prefill(const void* qkv, void* out, const int32_t* cu_
     return valle_attn_prefill_rowwise(qkv, out, cu_seqlens, B, M, H, Dh, causal, dtype, stream);
 }
 
+// ------------------------------------------------------------------ static scratch of valle_ar_decode_noalloc (below)
+#define VALLE_NOALLOC_SCRATCH_BYTES (2u << 20)
+static __device__ __align__(256) unsigned char scratch[VALLE_NOALLOC_SCRATCH_BYTES];
+#define VALLE_MAX_DEVICES 64
+static void* g_scratch_ptr[VALLE_MAX_DEVICES];       // per device: the device address of that GPU's copy of `scratch`
+static std::mutex g_scratch_mu;
+
+// Once per device, with that device current: the array's address ON THIS GPU.  Called from valle_model_create (the
+// library's set-up call: no stream capture can be active there) and, for a device no model was created on, from the
+// entry point's first call.
+static int scratch_resolve(int dev, void** out) {
+    VALLE_REQUIRE(dev >= 0 && dev < VALLE_MAX_DEVICES, VALLE_E_UNSUPPORTED, "valle_ar_decode_noalloc: device %d", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        VALLE_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        VALLE_REQUIRE(p != nullptr, VALLE_E_HIP, "valle_ar_decode_noalloc: no device address for the scratch array");
+        g_scratch_ptr[dev] = p;
+    }
+    if (out) *out = g_scratch_ptr[dev];
+    return VALLE_OK;
+}
+
 extern "C" void valle_model_destroy(valle_model* m);
 extern "C" int valle_model_create(const valle_config* cfg, const void* emb, const float* rope,
                                   const valle_layer_weights* layers_host, const void* final_norm,
@@ -43,6 +66,15 @@ extern "C" int valle_model_create(const valle_config* cfg, const void* emb, cons
         m->head_b[k] = head_b_host ? head_b_host[k] : nullptr;
         m->head_n[k] = head_n_host[k];
         m->head_pn[k] = head_pn_host ? head_pn_host[k] : nullptr;
+    }
+    // the no-allocation entry point's scratch address on this GPU is taken here, outside any stream capture
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        const int rc = scratch_resolve(dev, nullptr);
+        if (rc != VALLE_OK) { valle_model_destroy(m); return rc; }
+        m->device = dev;
+    } else {
+        m->device = -1;
     }
     *out = m;
     return VALLE_OK;
@@ -134,6 +166,8 @@ extern "C" int valle_forward_dense(valle_model* m, const int32_t* emb_idx, const
     VALLE_REQUIRE(m && emb_idx && pos && cu_seqlens && workspace, VALLE_E_ARG, "valle_forward_dense: null pointer");
     VALLE_REQUIRE(B > 0 && M > 0, VALLE_E_ARG, "valle_forward_dense: empty batch (B=%d, M=%d)", B, M);
     VALLE_REQUIRE(n_out == 0 || out_rows, VALLE_E_ARG, "valle_forward_dense: out_rows missing");
+    // the last layer runs its output projection and MLP on the n_out gathered rows inside buffers carved for M rows
+    VALLE_REQUIRE(n_out >= 0 && n_out <= M, VALLE_E_ARG, "valle_forward_dense: n_out %d outside 0..M (%d)", n_out, M);
     VALLE_REQUIRE(logits == nullptr || (head >= 0 && head < m->n_cls && ld_logits >= m->head_n[head]), VALLE_E_ARG,
                   "valle_forward_dense: bad head %d / ld_logits %d", head, ld_logits);
     const valle_config& c = m->cfg;
@@ -339,12 +373,6 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
 // valle_ar_decode_noalloc: valle_ar_decode with the step's activations in a static device array instead of a caller
 // workspace, for callers that cannot allocate (HIP graph capture, serving loops that forbid hipMalloc).  Nothing here
 // allocates: the array lives in the code object (each GPU the library runs on holds its own copy until the process ends).
-#define VALLE_NOALLOC_SCRATCH_BYTES (2u << 20)
-static __device__ __align__(256) unsigned char scratch[VALLE_NOALLOC_SCRATCH_BYTES];
-#define VALLE_MAX_DEVICES 64
-static void* g_scratch_ptr[VALLE_MAX_DEVICES];       // per device: the device address of that GPU's copy of `scratch`
-static std::mutex g_scratch_mu;
-
 extern "C" size_t valle_noalloc_scratch_bytes(void) { return VALLE_NOALLOC_SCRATCH_BYTES; }
 
 extern "C" int valle_ar_decode_noalloc(valle_model* m, const valle_ar_state* st, const valle_sample_params* sp,
@@ -355,19 +383,17 @@ extern "C" int valle_ar_decode_noalloc(valle_model* m, const valle_ar_state* st,
     VALLE_REQUIRE(need <= VALLE_NOALLOC_SCRATCH_BYTES, VALLE_E_WORKSPACE,
                   "valle_ar_decode_noalloc: %d utterances at d_model %d need %zu B of scratch, the static array holds %u B; "
                   "use valle_ar_decode with a caller workspace", st->B, m->cfg.d_model, need, VALLE_NOALLOC_SCRATCH_BYTES);
-    int dev = -1;
-    VALLE_HIP_CHECK(hipGetDevice(&dev));
-    VALLE_REQUIRE(dev >= 0 && dev < VALLE_MAX_DEVICES, VALLE_E_UNSUPPORTED, "valle_ar_decode_noalloc: device %d", dev);
-    void* ptr;
-    {
-        std::lock_guard<std::mutex> lock(g_scratch_mu);
-        if (!g_scratch_ptr[dev]) {          // once per device, with that device current: the array's address ON THIS GPU
-            void* p = nullptr;
-            VALLE_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
-            VALLE_REQUIRE(p != nullptr, VALLE_E_HIP, "valle_ar_decode_noalloc: no device address for the scratch array");
-            g_scratch_ptr[dev] = p;
-        }
-        ptr = g_scratch_ptr[dev];
+    // the array of the GPU the model was created on (its weights live there, so must the stream); a descriptor made
+    // before any device was current falls back to the current device, resolved now (call once outside capture then)
+    int dev = m->device;
+    if (dev < 0) VALLE_HIP_CHECK(hipGetDevice(&dev));
+    void* ptr = nullptr;
+    const int rcs = scratch_resolve(dev, &ptr);
+    if (rcs != VALLE_OK) return rcs;
+    if (stream) {                                    // a stream of another GPU would run the kernels on another GPU's array
+        int sdev = -1;
+        if (hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess)
+            VALLE_REQUIRE(sdev == dev, VALLE_E_ARG, "valle_ar_decode_noalloc: stream belongs to device %d, the model to device %d", sdev, dev);
     }
     // every byte of the workspace that a step reads was written earlier in the same step (or by the previous step's
     // sampler), so nothing has to be cleared; calls that overlap on one GPU share the array and race

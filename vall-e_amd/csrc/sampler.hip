@@ -339,7 +339,6 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
             }
         // prob_original = softmax(sorted) in fp32 (mx, se of the whole row are the sorted row's too)
         __shared__ int s_k;
-        __shared__ float s_sek;
         valle_mirostat_state* st = a.mirostat + item;
         if (tid == 0) {
             double num = 0.0, den = 0.0;
@@ -351,19 +350,31 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
                 num += log(b) * log(t);
                 den += log(t) * log(t);
             }
+            // degenerate results are reported as the reference meets them (k < 0, decoded by Base._sample_mirostat):
+            // -1 a division by zero (ZeroDivisionError), -2 a power of a negative base = a complex number in Python
+            // (round() raises TypeError; NaN here), -3 an infinite value (OverflowError), -4 an empty candidate slice
             int k = -1;
             if (!zero) {
                 const double s_hat = num / den, eps = s_hat - 1.0;
-                const double kf = pow((eps * pow(2.0, st->max_surprise)) / (1.0 - pow(st->n, -eps)), 1.0 / s_hat);
-                k = (kf == kf && kf < 1e9 && kf > -1e9) ? (int)rint(kf) + 1 : V;   // round(): half to even, like rint
-                k = k < 1 ? 1 : (k > V ? V : k);
+                const double dn = 1.0 - pow(st->n, -eps);
+                if (s_hat != 0.0 && dn != 0.0) {
+                    const double kf = pow((eps * pow(2.0, st->max_surprise)) / dn, 1.0 / s_hat);
+                    if (kf != kf) k = -2;
+                    else if (kf > 1.7e308 || kf < -1.7e308) k = -3;
+                    else {
+                        const double kr = rint(kf) + 1.0;                  // round(): half to even, like rint
+                        // sorted[0:k]: k above V keeps the row, k <= 0 counts from the end (Python slice)
+                        const double ke = kr > (double)V ? (double)V : (kr <= 0.0 ? (double)V + kr : kr);
+                        k = ke >= 1.0 ? (int)ke : -4;
+                    }
+                }
             }
             s_k = k;
         }
         __syncthreads();
         const int k = s_k;
         if (k < 0) {                                                   // ZeroDivisionError in the reference: nothing is drawn
-            if (tid == 0) { st->k = -1; st->token = 0; a.ids[row] = 0; if (a.scores) a.scores[row] = 0.f; }
+            if (tid == 0) { st->k = k; st->token = 0; a.ids[row] = 0; if (a.scores) a.scores[row] = 0.f; }
             return;
         }
         float sek = 0.f;

@@ -125,6 +125,14 @@ class TTS:
         self.device = torch.device(device if device is not None else "cuda")
         self.dtype = dtype if dtype is not None else torch.float32        # data/config.yaml:118 weight_dtype float32
         self.amp = bool(amp)
+        if self.amp and self.dtype != torch.float32:
+            # inference.py:96-98, :516: with amp the reference keeps fp32 weights and runs under torch.autocast(dtype): the
+            # linears compute in the low dtype on per-call casts, while embeddings, residual stream and norms stay fp32.
+            # That is other arithmetic than model.to(dtype) (the one low-precision form built here), so it is refused
+            # rather than silently replaced.  amp with dtype float32 is plain fp32 in the reference as well (autocast to
+            # float32 is a no-op), and is accepted.
+            raise NotImplementedError("amp=True with a low-precision dtype (fp32 master weights under autocast) is not built; "
+                                      "use amp=False with dtype=torch.bfloat16 (model.to(bfloat16) semantics)")
         self.batch_size = 16                                               # config.py:856
         self.tokenizer = None
         if state_dict is None:

@@ -3,7 +3,7 @@ from .ar_nar import AR_NAR
 from .base import Base, Logits, Sampled
 
 
-def get_model(config, training=False, **model_kwargs):
+def get_model(config, training=True, **model_kwargs):
     if getattr(config, "version", 5) >= 7:
         raise NotImplementedError("AR_NAR_V2 (version >= 7) is a different model family; not built")
     kw = dict(

@@ -650,8 +650,11 @@ class Base:
                                           C.byref(params), L.ptr(dev_states), L.ptr(ids), L.ptr(scores), L.stream_ptr(self.device)))
         back = (L.MirostatState * B).from_buffer_copy(dev_states.cpu().numpy().tobytes()[:nbytes])
         for st, b in zip(mirostat, back):
-            if b.k < 0:
-                raise ZeroDivisionError("float division by zero")               # compute_k, samplers.py:202 (e.g. top_no left -inf behind)
+            if b.k < 0:                                                       # compute_k's failures, as Python meets them
+                raise {-1: ZeroDivisionError("float division by zero"),         # samplers.py:202 / :209 (e.g. top_no left -inf behind)
+                       -2: TypeError("type complex doesn't define __round__ method"),   # negative base ** fraction, :209-210
+                       -3: OverflowError("cannot convert float infinity to integer"),   # :210
+                       }.get(b.k, RuntimeError("mirostat: empty candidate set (sorted_logits[0:k] with k <= -vocab)"))
             st.update(index_surprise=b.index_surprise, running_total_surprise=b.running_total_surprise,
                       error_surprise=b.error_surprise, max_surprise=b.max_surprise,
                       token=torch.tensor([b.token], device=self.device), k=b.k)
