@@ -294,6 +294,20 @@ int valle_forward_dense(valle_model* m, const int32_t* emb_idx, const int32_t* p
                         const int32_t* out_rows, int n_out, int head, float* logits, int ld_logits,
                         void* hidden_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* valle_forward_dense that also returns the LAST layer's raw attention products of chosen rows: scores[r][h][j] =
+ * q[score_rows[r]][h] . k[j][h] / sqrt(head_dim) for every row j of that row's utterance, fp32 [n_score][H][ld_scores]
+ * (ld_scores >= max_T) -- what the reference's attention hands back under output_attentions (models/arch/llama.py:429,
+ * :469-477: the scaled products BEFORE mask and softmax; for a bf16 model the product is rounded to bf16 first, as
+ * torch.matmul's output is).  The entropix sampler reads the newest row of the last layer (samplers.py:294, :482);
+ * the earlier layers' maps are not materialised. */
+int valle_forward_dense_scores(valle_model* m, const int32_t* emb_idx, const int32_t* pos,
+                               const int32_t* cu_seqlens, int B, int M, int max_T, int causal,
+                               void* kcache, void* vcache, int cache_T, size_t cache_layer_stride,
+                               const int32_t* cache_slot, const int32_t* cache_pos0,
+                               const int32_t* out_rows, int n_out, int head, float* logits, int ld_logits,
+                               void* hidden_out, void* workspace, size_t workspace_bytes, void* stream,
+                               const int32_t* score_rows, int n_score, float* scores, int ld_scores);
+
 /* Device-resident AR state (one per batch). All arrays are caller-allocated device memory. */
 typedef struct {
     int B;
@@ -338,13 +352,47 @@ int valle_ar_decode(valle_model* m, const valle_ar_state* st, const valle_sample
                     int n_steps, float* logits_out, int ld_logits,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* One logits-only decode step (valle_ar_decode with sp == NULL, n_steps 1) that also returns the last layer's raw attention
+ * products of every utterance's newest row against its ctx_len[b] + 1 cached keys: scores [B][H][ld_scores] fp32,
+ * ld_scores >= max_ctx + 1 (same values as valle_forward_dense_scores gives for that row of a recompute).
+ * = Base.forward(..., output_attentions=True) of the entropix AR loop (models/ar_nar.py:778-783). */
+int valle_ar_decode_scores(valle_model* m, const valle_ar_state* st, float* logits_out, int ld_logits,
+                           float* scores, int ld_scores, void* workspace, size_t workspace_bytes, void* stream);
+
+/* calculate_entropix_metrics (samplers.py:281-321) as sample_entropix calls it (:482): per utterance b, on the logits row
+ * logit_row[b] (NULL: row b) of logits [..][ld] and its scores [b][H][ld_scores] over n_keys[b] keys:
+ * out[b][0..5] = logits entropy, logits varentropy (bits), attention entropy (mean over heads), its unbiased variance over
+ * heads (NaN -> 0), agreement, interaction strength; out is [B][8] fp32 (6, 7 unused). */
+int valle_entropix_metrics(const float* logits, int ld, int vocab, const int32_t* logit_row, const float* scores,
+                           int ld_scores, int H, const int32_t* n_keys, int B, float* out, void* stream);
+
+/* acc[b][v] (+)= sum over rows [row_off[b], row_off[b+1]) of log_softmax(logits[row])[v] (accumulate = 0 overwrites): the
+ * adaptive entropix branch scores a draw by the sum over ALL rows of the sequence of log_softmax[row][token]
+ * (samplers.py:516, :527-545); the decode loop keeps that sum per utterance and adds the newest row each step. */
+int valle_logsoftmax_colsum(const float* logits, int ld, int vocab, const int32_t* row_off, int B, float* acc,
+                            int ld_acc, int accumulate, void* stream);
+
+/* _sample_entropix (samplers.py:419-462) per utterance on logits row logit_row[b]: probabilities at temperature[b], the
+ * top_k[b] largest in ascending order, the top_p[b] cut of :452, n_draws[b] <= max_draws draws argmax(p / q) with
+ * q ~ Exponential(1) (noise == NULL: Philox of (seed, offset); else q = noise[(b * max_draws + draw) * ld_noise + i] for
+ * ascending position i), and of those draws the one with the largest colsum[b][token] (first on ties; samplers.py:547-550;
+ * colsum NULL: the first draw).  temperature / top_k / top_p arrive clamped as :433-436 does (the host does the branch
+ * arithmetic of :489-523).  ids [B] the winner, draws [B][max_draws] every draw's token, forced (optional) [B][ld_forced] =
+ * -inf except 0 at the winner -- a greedy valle_sample_append on it appends it. */
+int valle_entropix_pick(const float* logits, int ld, int vocab, const int32_t* logit_row, int B,
+                        const float* temperature, const int32_t* top_k, const float* top_p, const int32_t* n_draws,
+                        int max_draws, const float* colsum, int ld_colsum, const float* noise, int ld_noise,
+                        uint64_t seed, uint64_t offset, int32_t* ids, int32_t* draws, float* forced, int ld_forced,
+                        void* stream);
+
 /* valle_ar_decode for callers that cannot allocate device memory (code under HIP graph capture, serving loops and
  * harnesses that forbid hipMalloc) and so cannot bring a workspace.  NO COUNTERPART IN THE REFERENCE: the reference has
  * no such entry; it exists for those callers only.  Same arguments, results and errors as valle_ar_decode without the
  * workspace pair: the step's activations live in a static device array of valle_noalloc_scratch_bytes() = 2 MiB inside
  * the library (every GPU the library runs on holds its own copy until the process ends).  Batches whose
  * valle_decode_workspace_bytes() exceeds that are refused with VALLE_E_WORKSPACE (32 utterances at d_model 1024 in bf16
- * need 1.3 MB).  Calls no hipMalloc / hipFree.  All calls on one GPU share the array: calls that overlap on one GPU
+ * need 1.3 MB).  Calls no hipMalloc / hipFree; the array's device address on a GPU is taken in valle_model_create (with that
+ * GPU current, outside any stream capture), and a stream of another GPU than the model's is refused.  All calls on one GPU share the array: calls that overlap on one GPU
  * (two streams, two threads) race -- serialise them or use valle_ar_decode with separate workspaces. */
 size_t valle_noalloc_scratch_bytes(void);
 int valle_ar_decode_noalloc(valle_model* m, const valle_ar_state* st, const valle_sample_params* sp,

@@ -912,6 +912,85 @@ def scen_mirostat_kat():
     save("mirostat_kat", **d)
 
 
+METRIC_KEYS = ("logits_entropy", "logits_varentropy", "attn_entropy", "attn_varentropy", "agreement", "interaction_strength", "action")
+
+
+def scen_entropix():
+    """Entropix (samplers.py:281-566; wired at models/base.py:1325-1342, models/ar_nar.py:782, :807).
+    entropix_kat: the reference's sample_entropix on synthetic (logits, attentions) pairs built to reach each branch --
+    near one-hot (branch 0: the reference raises IndexError there), uniform (1), one dominant token over a flat tail (2, 3),
+    random normal (4) -- with top_k 27 (real draws, torch.manual_seed per case) and with the default top_k of -100 (which the
+    clamp of _sample_entropix turns into 1: the pick is the arg-max).
+    tiny_entropix: the AR loop with entropix_sampling=True on the tiny model: default top_k (deterministic) with the metrics
+    of every step, and top_k 27 / temperature 0.8 under torch.manual_seed (the draws are torch's global stream)."""
+    ref = rh.load_reference()
+    import vall_e.models.base as rb
+    g = torch.Generator().manual_seed(2024)
+    V, T, H, Lyr = 1025, 7, 4, 2
+    def dominant(p0):
+        lg = torch.full((V,), math.log((1 - p0) / (V - 1)))
+        lg[37] = math.log(p0)
+        return lg
+    import math
+    rows = {
+        "onehot": torch.cat([torch.tensor([40.0]), torch.zeros(V - 1)]),
+        "uniform": torch.randn(V, generator=g) * 0.01,
+        "dom07": dominant(0.7) + torch.randn(V, generator=g) * 0.01,
+        "dom04": dominant(0.4) + torch.randn(V, generator=g) * 0.01,
+        "normal": torch.randn(V, generator=g) * 2.0,
+        "normal_b": torch.randn(V, generator=g) * 1.0,
+    }
+    d = {"cases": np.array(list(rows))}
+    for ci, (name, last) in enumerate(rows.items()):
+        logits = torch.cat([torch.randn(T - 1, V, generator=g), last[None, :]])
+        att = torch.randn(Lyr, H, T, T, generator=g) * (0.5 + ci)
+        d[f"logits_{name}"], d[f"att_{name}"] = logits, att
+        for tag, top_k, temp in (("k27", 27, 0.9), ("kdef", -100, 1.0)):
+            torch.manual_seed(500 + ci)
+            try:
+                tok, met = ref.samplers.sample_entropix(logits.clone(), att.clone(), temp, top_k, 0.95, 0.0)
+                d[f"tok_{name}_{tag}"] = tok.reshape(-1)
+                d[f"met_{name}_{tag}"] = np.array([float(met[k]) for k in METRIC_KEYS])
+                print(f"  [entropix_kat] {name} {tag}: action {met['action']} token {tok.tolist()}")
+            except IndexError as e:
+                d[f"raises_{name}_{tag}"] = np.int64(1)
+                print(f"  [entropix_kat] {name} {tag}: IndexError ({e})")
+    d["seed_base"] = np.int64(500)
+    d["top_p"] = np.float64(0.95)
+    save("entropix_kat", **d)
+
+    model, mcfg = get_ref_model("tiny")
+    phns, proms, langs = synth_batch(31, 2, n_phn=11, n_prom=18, ragged=True)
+    steps = 6
+    out = input_arrays(phns, proms, langs)
+    log = []
+    orig = rb.sample_entropix
+    def wrapped(logits, attentions, *a, **k):
+        r = orig(logits, attentions, *a, **k)
+        log.append((np.array([float(r[1][k_]) for k_ in METRIC_KEYS]), attentions[-1, :, -1, :].float().clone(), logits[-1].float().clone()))
+        return r
+    rb.sample_entropix = wrapped
+    try:
+        codes = run_ar(model, phns, proms, langs, max_duration=steps, temperature=1.0, entropix_sampling=True)
+        out.update(pack_list("ar_codes", codes))
+        out["metrics"] = np.stack([m for m, _, _ in log]).reshape(steps, 2, len(METRIC_KEYS))
+        for n in range(steps):
+            for b in range(2):
+                out[f"scores_{n}_{b}"] = log[n * 2 + b][1]           # last layer, newest row: (H, T) raw scaled products
+        out["last_logits"] = torch.stack([l for _, _, l in log]).reshape(steps, 2, -1)
+        log.clear()
+        torch.manual_seed(77)
+        codes = run_ar(model, phns, proms, langs, max_duration=steps, temperature=0.8, top_k=27, top_p=0.9, entropix_sampling=True)
+        out.update(pack_list("ar_codes_k27", codes))
+        out["metrics_k27"] = np.stack([m for m, _, _ in log]).reshape(steps, 2, len(METRIC_KEYS))
+    finally:
+        rb.sample_entropix = orig
+    out["steps"] = np.int64(steps)
+    out["seed_k27"] = np.int64(77)
+    print("  [tiny_entropix] codes", [c.tolist() for c in codes], "actions", out["metrics"][:, :, -1].tolist())
+    save("tiny_entropix", **out)
+
+
 def scen_full_b3():
     mk = lambda s: synth_batch(s, 3, n_phn=30, n_prom=60, ragged=True)
     ar_nar_scenario("full_b3", "full", mk, 61, steps=12)
@@ -966,6 +1045,7 @@ SCENARIOS = {
     "qnt_kat": scen_qnt_kat,
     "tiny_beam": scen_tiny_beam,
     "mirostat_kat": scen_mirostat_kat,
+    "entropix": scen_entropix,
     "full_b1": scen_full_b1,
     "long": scen_long,
     "full_b3": scen_full_b3,

@@ -274,6 +274,108 @@ def mirostat_sample(logits, state, generator=None, forced_index=None):
     return state
 
 
+# ---------------------------------------------------------------------------- entropix (samplers.py:281-566)
+LN_2 = 0.69314718056                                                       # samplers.py:278
+
+# samplers.py:364-414 (EntropixSamplerConfig): thresholds, coefficients and clamps of the five branches
+ENTROPIX = dict(
+    min_p=0.01, low_ent_thresh=0.1, low_vent_thresh=0.1, med_ent_thresh=3.0, high_ent_thresh=5.0, high_vent_thresh=5.0,
+    helv_attn_ent_offset=1.3, helv_attn_ent_coef=0.2, lehv_interaction_strength_offset=1.2, lehv_interaction_strength_coef=0.3,
+    hehv_attn_ent_coef=0.2, hehv_attn_vent_offset=2.0, hehv_attn_vent_coef=0.5, n_adaptive_samples=5,
+    ada_temp_logits=0.3, ada_temp_attn=0.2, ada_temp_agree=0.2, ada_top_p=0.1, ada_top_k_int=0.3, ada_top_k_agree=0.2,
+    ada_min_p=0.5, temperature_max=1.25, temperature_min=0.5, top_k_min=1, top_k_max=1024, top_p_min=0.1, top_p_max=1.0,
+    min_p_min=0.01, min_p_max=0.5)
+
+
+def entropix_metrics(last_logits, last_scores):
+    """samplers.py:281-321 as sample_entropix calls it (:482): last_logits (V,) = the newest row's logits, last_scores
+    (H, T) = the LAST layer's raw attention scores q.k / sqrt(Dh) of that row (what Attention.forward returns under
+    output_attentions: the scaled products BEFORE mask and softmax, arch/llama.py:429, :469-477).  The scores are
+    soft-maxed here (:295); entropy over keys per head, its unbiased variance over heads, the mean absolute deviation
+    of the heads from their mean, the mean |score|."""
+    log_probs = F.log_softmax(last_logits[None, :], dim=-1)
+    probs = torch.exp(log_probs)
+    entropy = -torch.sum(probs * log_probs, dim=-1) / LN_2
+    varentropy = torch.sum(probs * (log_probs / LN_2 + entropy.unsqueeze(-1)) ** 2, dim=-1)
+    sc = last_scores[None, :, None, :]                                       # (1, H, 1, T)
+    ap = F.softmax(sc, dim=-1)
+    attn_entropy = -torch.sum(ap * torch.log2(torch.clamp(ap, 1e-10, 1.0)), dim=-1)     # (1, H, 1)
+    attn_varentropy = torch.var(attn_entropy, dim=1)
+    attn_varentropy = torch.where(torch.isnan(attn_varentropy), torch.zeros_like(attn_varentropy), attn_varentropy)
+    mean_attention = torch.mean(ap, dim=1)
+    agreement = torch.mean(torch.abs(ap - mean_attention.unsqueeze(1)), dim=(1, 2))
+    interaction = torch.mean(torch.abs(sc), dim=(1, 2, 3))
+    return {"logits_entropy": torch.mean(entropy).item(), "logits_varentropy": torch.mean(varentropy).item(),
+            "attn_entropy": torch.mean(attn_entropy).item(), "attn_varentropy": torch.mean(attn_varentropy).item(),
+            "agreement": torch.mean(agreement).item(), "interaction_strength": interaction.item(), "action": -1}
+
+
+def entropix_pick(logit, temperature, top_k, top_p, min_p, noise=None):
+    """_sample_entropix (samplers.py:419-462) on the newest row: probabilities at the clamped temperature, the top_k
+    largest in ASCENDING order, those whose smaller neighbours already hold more than top_p dropped (:452), then
+    argmax(p / q), q ~ Exponential(1).  The min_p block (:441-444) edits ``logit`` after ``probs`` was taken from it and
+    so changes nothing.  noise: q for the ascending positions (tests); None draws from torch's global stream exactly as the
+    reference does."""
+    C = ENTROPIX
+    if top_k == 0:
+        top_k = logit.shape[-1]
+    temperature = clamp(float(temperature), C["temperature_min"], C["temperature_max"])
+    top_p = clamp(float(top_p), C["top_p_min"], C["top_p_max"])
+    top_k = clamp(int(top_k), C["top_k_min"], C["top_k_max"])
+    probs = F.softmax(logit / temperature, dim=-1)
+    top_probs, top_idx = torch.topk(probs, k=min(top_k, probs.shape[-1]))
+    ps, pi = torch.flip(top_probs, dims=[-1]), torch.flip(top_idx, dims=[-1])
+    csum = torch.cumsum(ps, dim=-1)
+    ps = ps * (1 - torch.where(csum - ps > top_p, torch.tensor(1.0), torch.tensor(0.0)))
+    ps = ps / torch.sum(ps, dim=-1, keepdim=True)
+    q = torch.distributions.exponential.Exponential(1.0).sample(ps.shape) if noise is None else noise[: ps.shape[-1]]
+    nxt = torch.argmax(ps / q, dim=-1, keepdim=True)
+    return torch.take_along_dim(pi, nxt, dim=-1)
+
+
+def sample_entropix(logits, last_scores, temperature=1.0, top_k=27, top_p=1.0, min_p=0.0, noise=None):
+    """sample_entropix (samplers.py:464-566) for one utterance: logits (T, V) of every row, last_scores (H, T) as in
+    entropix_metrics.  Returns (token tensor (1,), metrics dict with the branch taken in "action").  Branch 0 of the
+    reference calls ``logits[-1, :].argmax(dim=1)`` on a 1-D row and dies of an IndexError (:492): reproduced.  The
+    adaptive branch scores its five draws by sum over ALL rows of log_softmax[row, token] plus a constant (:527-545).
+    noise: list of per-draw q vectors (tests)."""
+    C = ENTROPIX
+    m = entropix_metrics(logits[-1], last_scores)
+    ent, vent = m["logits_entropy"], m["logits_varentropy"]
+    a_ent, a_vent, agree, inter = m["attn_entropy"], m["attn_varentropy"], m["agreement"], m["interaction_strength"]
+    nz = (lambda i: None) if noise is None else (lambda i: noise[i])
+    last = logits[-1, :]
+    if ent < C["low_ent_thresh"] and vent < C["low_vent_thresh"]:
+        m["action"] = 0
+        raise IndexError("Dimension out of range (expected to be in range of [-1, 0], but got 1)")
+    elif ent > C["high_ent_thresh"] and vent < C["low_vent_thresh"]:
+        m["action"] = 1
+        temperature *= C["helv_attn_ent_offset"] + C["helv_attn_ent_coef"] * a_ent
+        res = entropix_pick(last, temperature, top_k, top_p, min_p, nz(0))
+    elif ent < C["high_ent_thresh"] and vent > C["high_vent_thresh"]:
+        m["action"] = 2
+        temperature *= C["lehv_interaction_strength_offset"] + C["lehv_interaction_strength_coef"] * inter
+        top_k = max(5, int(top_k * (1 + 0.5 * (1 - agree))))
+        res = entropix_pick(last, temperature, top_k, top_p, min_p, nz(0))
+    elif ent > C["med_ent_thresh"] and vent > C["high_vent_thresh"]:
+        m["action"] = 3
+        temperature *= C["hehv_attn_vent_offset"] + C["hehv_attn_vent_coef"] * a_vent
+        top_p = max(0.5, top_p - C["hehv_attn_ent_coef"] * a_ent)
+        res = entropix_pick(last, temperature, top_k, top_p, min_p, nz(0))
+    else:
+        m["action"] = 4
+        log_softmax = F.log_softmax(logits, dim=-1)
+        lu, au = ent + vent, a_ent + a_vent
+        temperature *= 1 + C["ada_temp_logits"] * lu + C["ada_temp_attn"] * au - C["ada_temp_agree"] * agree
+        top_p = top_p * (1 + C["ada_top_p"] * a_vent)
+        top_k = round(float(top_k * (1 + C["ada_top_k_int"] * inter - C["ada_top_k_agree"] * agree)))
+        min_p = C["min_p"] * (1 - C["ada_min_p"] * lu)
+        samples = [entropix_pick(last, temperature, top_k, top_p, min_p, nz(i)) for i in range(C["n_adaptive_samples"])]
+        scores = [torch.sum(log_softmax[:, int(smp[0])]) for smp in samples]     # (+ one constant for all five)
+        res = samples[int(torch.argmax(torch.stack(scores)))]
+    return res, m
+
+
 def sample(logits, prev_list=None, quant_levels=None, *, causal_size=1, stop_token=1024, generator=None,
            temperature=1.0, min_temperature=-1.0, top_k=-100, top_p=1.0, min_p=0.0,
            repetition_penalty=1.0, repetition_penalty_decay=0.0, length_penalty=0.0, top_no=1.0,
@@ -462,7 +564,7 @@ class Oracle:
         rot = torch.cat((-x[..., h:], x[..., :h]), dim=-1)
         return x * cos + rot * sin
 
-    def stack(self, x, pos, lens, kv=None, layer_probe=None, causal=None):
+    def stack(self, x, pos, lens, kv=None, layer_probe=None, causal=None, score_probe=None):
         """x: packed (sum(lens), d); pos: packed position ids; lens: rows per utterance.
         kv: optional list (per layer) of per-utterance [K, V] caches that are appended to
         (KV-cache mode); attention then runs each new row against cache + new rows.
@@ -498,6 +600,8 @@ class Oracle:
                 if causal is None or causal[b]:
                     mask = mask.tril(diagonal=past)
                 att = (qb @ kb.transpose(1, 2)) * scale
+                if score_probe is not None and l == self.L - 1:              # output_attentions: the raw scaled products of the
+                    score_probe.append(att[:, -1, :].float().clone())        # newest row, (H, T) (arch/llama.py:429, :469-477)
                 att = att.masked_fill(~mask, float("-inf"))
                 att = torch.softmax(att.float(), dim=-1).to(qb.dtype)
                 outs.append((att @ vb).transpose(0, 1).reshape(n, self.d))
@@ -525,11 +629,11 @@ class Oracle:
         return head in ("phn", "len") or head.startswith("AR:")
 
     # -- one forward over a batch of plans: list of (T_i, V) logits (Base.forward) --------------
-    def forward(self, plans, rows=None, probe=None):
+    def forward(self, plans, rows=None, probe=None, score_probe=None):
         xs = [self.embed_sequence(p) for p in plans]
         lens = [x.shape[0] for x in xs]
         hid = self.stack(torch.cat(xs), torch.cat([p.pos for p in plans]), lens, layer_probe=probe,
-                         causal=[self.is_causal(p.head) for p in plans])
+                         causal=[self.is_causal(p.head) for p in plans], score_probe=score_probe)
         out, o = [], 0
         for i, (p, n) in enumerate(zip(plans, lens)):
             hi = hid[o:o + n]
@@ -590,6 +694,9 @@ class Oracle:
         refine_on_stop = kw.pop("refine_on_stop", False)
         prefix_silence = kw.pop("prefix_silence", 0.0)
         beam_width = kw.get("beam_width", 0)
+        entropix = kw.pop("entropix_sampling", False)                        # ar_nar.py:782, :807; base.py:1325-1342
+        entropix_noise = kw.pop("entropix_noise", None)                      # tests: [step][utterance] -> list of q vectors
+        self.entropix_log = []                                               # the metrics dicts, per step and utterance
         B = len(phns)
         self.use_lora = kw.pop("use_lora", None)
         self.set_lora_level(0)                                           # ar_nar.py:619-620
@@ -622,8 +729,19 @@ class Oracle:
                 logits = cfg_combine(logits, null, cfg_strength, [len(s) + 1 for s in seqs], cfg_rescale)
             if return_logits:
                 last_logits.append(torch.stack([l[-1].float() for l in logits]))
-            ids, _, _ = sample(logits, prev_list=seqs, causal_size=self.causal_size, stop_token=self.stop_token,
-                               generator=generator, **kw)
+            if entropix:
+                # the whole sequence's logits and the last layer's raw scores go to sample_entropix, nothing else of the
+                # sampler chain runs (base.py:1327-1342)
+                probe = []
+                full = self.forward(self._plans(phns, langs, proms, seqs, 0), score_probe=probe)
+                got = [sample_entropix(full[i].float(), probe[i], kw.get("temperature", 1.0), kw.get("top_k", -100),
+                                       kw.get("top_p", 1.0), kw.get("min_p", 0.0),
+                                       None if entropix_noise is None else entropix_noise[n][i]) for i in range(B)]
+                ids = [g[0] for g in got]
+                self.entropix_log.append([g[1] for g in got])
+            else:
+                ids, _, _ = sample(logits, prev_list=seqs, causal_size=self.causal_size, stop_token=self.stop_token,
+                                   generator=generator, **kw)
             if beam_width > 0 and B == 1:                                    # ar_nar.py:821-832: first step, the batch becomes the
                 B = beam_width                                               # beam (the language list is NOT expanded there: with
                 if langs is not None and B > 1:                              # one the reference dies of an IndexError next step)

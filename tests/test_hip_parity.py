@@ -444,6 +444,99 @@ def test_mirostat_state_and_draws(gpu_device):
         m.sample(logits=lg, prev_list=None, mirostat=[dict(base)], temperature=0.9)   # compute_k divides by zero (samplers.py:202)
 
 
+ENTROPIX_KEYS = ("logits_entropy", "logits_varentropy", "attn_entropy", "attn_varentropy", "agreement", "interaction_strength", "action")
+
+
+def _entropix_noise(seed, plan):
+    """The Exponential(1) variates the reference draws under torch.manual_seed(seed): one vector of k per draw, in call
+    order; plan = [(k, draws), ...] per sampled utterance in that order -> list of (5, 1024) tensors (unused slots 1.0)."""
+    torch.manual_seed(seed)
+    out = []
+    for k, draws in plan:
+        q = torch.ones(5, 1024)
+        for dr in range(draws):
+            q[dr, :k] = torch.distributions.exponential.Exponential(1.0).sample((k,))
+        out.append(q)
+    return out
+
+
+def test_entropix_known_answers(gpu_device):
+    """Base.sample(attentions=...) -> valle_entropix_metrics / valle_logsoftmax_colsum / valle_entropix_pick against the
+    reference's own sample_entropix outputs (golden entropix_kat: inputs that reach every branch; samplers.py:281-566):
+    metrics 1e-4, the branch, and the token -- with the default top_k (the clamp of :435 turns -100 into 1: the pick is
+    deterministic) and with top_k 27, where the reference's draws are replayed (same seed, same torch CPU stream) and handed
+    to the kernel as its noise.  Branch 0 raises IndexError as in the reference (:492)."""
+    from vall_e_amd.models.base import Base
+    z = load_golden("entropix_kat")
+    m = hip_model("tiny")
+    m._prepare()
+    for ci, name in enumerate(z["cases"].tolist()):
+        logits, att = torch.from_numpy(z[f"logits_{name}"]), torch.from_numpy(z[f"att_{name}"])
+        atts = [att[l][None] for l in range(att.shape[0])]                     # per layer (B = 1, H, T, T), as the reference's forward returns
+        for tag, top_k, temp in (("k27", 27, 0.9), ("kdef", -100, 1.0)):
+            kw = dict(temperature=temp, top_k=top_k, top_p=float(z["top_p"]), attentions=atts)
+            if f"raises_{name}_{tag}" in z:
+                with pytest.raises(IndexError):
+                    m.sample(logits=[logits], **kw)
+                continue
+            want = z[f"met_{name}_{tag}"]
+            _, _, k, _, draws = Base.entropix_branch(dict(zip(ENTROPIX_KEYS[:6], want[:6].tolist())), temp, top_k, float(z["top_p"]), 1025)
+            noise = torch.stack(_entropix_noise(int(z["seed_base"]) + ci, [(k, draws)]))
+            out = m.sample(logits=[logits], entropix_noise=noise, **kw)
+            got = [out.entropy[0][key] for key in ENTROPIX_KEYS]
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5, err_msg=f"{name} {tag}")
+            assert out.ids[0].tolist() == z[f"tok_{name}_{tag}"].tolist(), (name, tag, out.entropy[0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_tiny_entropix_ar(gpu_device, dtype):
+    """forward_ar(entropix_sampling=True) (models/ar_nar.py:782, :807; models/base.py:1325-1342) on the KV-cache path.  fp32:
+    the last layer's raw attention products of the newest row == the reference's at every step (1e-4), the metrics too, the
+    codes identical -- with the default top_k, and with top_k 27 under the reference's replayed draws;
+    forward_super(output_attentions=True) gives the same products for a recompute of the final sequence.  bf16: the
+    attention products agree with the fp32 reference within the bf16 tolerance and the loop runs (the reference's
+    arithmetic on bf16 attention tensors is not reproduced bit for bit)."""
+    from vall_e_amd.models.base import Base
+    z = load_golden("tiny_entropix")
+    phns, proms, langs = golden_inputs(z)
+    steps = int(z["steps"])
+    m = hip_model("tiny", dtype)
+    trace = []
+    kw = dict(task_list=["tts"] * 2, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=steps, entropix_sampling=True)
+    codes = m(temperature=1.0, trace=trace, **kw)
+    assert len(trace) == steps
+    got = np.array([[[mm[k] for k in ENTROPIX_KEYS] for mm in step] for step in trace])
+    if dtype == torch.bfloat16:
+        assert all(c.shape[0] == steps for c in codes)
+        np.testing.assert_allclose(got[0, :, :6], z["metrics"][0, :, :6], rtol=0.1, atol=5e-3)   # step 0: same inputs on both sides
+        return
+    np.testing.assert_allclose(got, z["metrics"], rtol=2e-4, atol=2e-5)
+    for b in range(2):
+        np.testing.assert_array_equal(codes[b].cpu().numpy(), z[f"ar_codes_{b}"])
+    # the products themselves, through the lower-level surface: recompute of the sequence before the last step
+    resp = [torch.from_numpy(z[f"ar_codes_{b}"][: steps - 1]) for b in range(2)]
+    out = m.forward_super(dict(phns_list=phns, lang_list=langs, proms_list=proms, resps_list=resp), quant_levels=[0, 0], output_attentions=True)
+    for b in range(2):
+        want = torch.from_numpy(z[f"scores_{steps - 1}_{b}"])
+        T = want.shape[1]
+        torch.testing.assert_close(out.attentions[-1][b, :, T - 1, :T].cpu(), want, rtol=1e-4, atol=1e-5)
+    # top_k 27: real draws.  The reference consumed torch's global stream in (step, utterance, draw) order
+    plan = [Base.entropix_branch(dict(zip(ENTROPIX_KEYS[:6], z["metrics_k27"][n, b, :6].tolist())), 0.8, 27, 0.9, 1025)[2::2]
+            for n in range(steps) for b in range(2)]
+    flat = _entropix_noise(int(z["seed_k27"]), plan)
+    noise = [torch.stack(flat[2 * n: 2 * n + 2]) for n in range(steps)]
+    trace2 = []
+    codes = m(temperature=0.8, top_k=27, top_p=0.9, entropix_noise=noise, trace=trace2, **kw)
+    got = np.array([[[mm[k] for k in ENTROPIX_KEYS] for mm in step] for step in trace2])
+    np.testing.assert_allclose(got, z["metrics_k27"], rtol=2e-4, atol=2e-5)
+    for b in range(2):
+        np.testing.assert_array_equal(codes[b].cpu().numpy(), z[f"ar_codes_k27_{b}"])
+    # without injected noise the draws come from the Philox stream of `seed`: reproducible, and dependent on the seed
+    a = m(temperature=0.8, top_k=27, top_p=0.9, seed=3, **kw)
+    b_ = m(temperature=0.8, top_k=27, top_p=0.9, seed=3, **kw)
+    assert all(torch.equal(x, y) for x, y in zip(a, b_))
+
+
 def test_tiny_beam_search(gpu_device):
     """beam_width=3 on one utterance without a language list (the only form the version-5 reference can run,
     models/ar_nar.py:821-842, :865-867; models/base.py:1412-1415): codes == the reference's."""

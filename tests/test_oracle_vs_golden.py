@@ -482,3 +482,46 @@ def test_long_sequences_oracle():
     codes, last = o.ar(phns, proms, langs, max_duration=40, temperature=0.0, use_cache=True, return_logits=True)
     np.testing.assert_array_equal(codes[0].numpy(), z["ar_codes_0"][:40])
     assert_close(torch.stack(last), z["ar_last_logits"][:40], 5e-4, 5e-4)
+
+
+# ------------------------------------------------------------------------------ entropix (samplers.py:281-566)
+ENTROPIX_KEYS = ("logits_entropy", "logits_varentropy", "attn_entropy", "attn_varentropy", "agreement", "interaction_strength", "action")
+
+
+def test_entropix_known_answers():
+    """The restatement of sample_entropix against the reference's own outputs on inputs that reach every branch
+    (goldens from oracle/gen_golden.py:scen_entropix): metrics 1e-5, the branch taken, and -- drawing from torch's global
+    stream under the same seed, as the reference does -- the same token.  Branch 0 raises IndexError, as the reference."""
+    import valle_oracle as vo
+    z = load_golden("entropix_kat")
+    for ci, name in enumerate(z["cases"].tolist()):
+        logits, att = torch.from_numpy(z[f"logits_{name}"]), torch.from_numpy(z[f"att_{name}"])
+        for tag, top_k, temp in (("k27", 27, 0.9), ("kdef", -100, 1.0)):
+            torch.manual_seed(int(z["seed_base"]) + ci)
+            if f"raises_{name}_{tag}" in z:
+                with pytest.raises(IndexError):
+                    vo.sample_entropix(logits, att[-1, :, -1, :], temp, top_k, float(z["top_p"]), 0.0)
+                continue
+            tok, met = vo.sample_entropix(logits, att[-1, :, -1, :], temp, top_k, float(z["top_p"]), 0.0)
+            want = z[f"met_{name}_{tag}"]
+            np.testing.assert_allclose([met[k] for k in ENTROPIX_KEYS], want, rtol=1e-5, atol=1e-6, err_msg=f"{name} {tag}")
+            assert tok.tolist() == z[f"tok_{name}_{tag}"].tolist(), (name, tag)
+
+
+def test_tiny_entropix_ar():
+    """The AR loop with entropix_sampling=True (models/ar_nar.py:782, :807; models/base.py:1325-1342): codes, per-step metrics
+    and the last layer's raw attention scores of the newest row equal the reference's; with top_k 27 the draws come from
+    torch's global stream, so the same manual_seed gives the same codes."""
+    z = load_golden("tiny_entropix")
+    phns, proms, langs = golden_inputs(z)
+    o = make_oracle("tiny")
+    steps = int(z["steps"])
+    out = o.ar(phns, proms, langs, max_duration=steps, temperature=1.0, entropix_sampling=True)
+    for b in range(2):
+        np.testing.assert_array_equal(out[b].numpy(), z[f"ar_codes_{b}"])
+    got = np.array([[[m[k] for k in ENTROPIX_KEYS] for m in step] for step in o.entropix_log])
+    np.testing.assert_allclose(got, z["metrics"], rtol=2e-4, atol=2e-5)
+    torch.manual_seed(int(z["seed_k27"]))
+    out = o.ar(phns, proms, langs, max_duration=steps, temperature=0.8, top_k=27, top_p=0.9, entropix_sampling=True)
+    for b in range(2):
+        np.testing.assert_array_equal(out[b].numpy(), z[f"ar_codes_k27_{b}"])

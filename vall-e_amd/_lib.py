@@ -93,6 +93,16 @@ SIGNATURES = {
     "valle_forward_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p,
                                     c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "valle_forward_dense_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                           c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p,
+                                           c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p,
+                                           c_void_p, c_int, c_void_p, c_int]),
+    "valle_ar_decode_scores": (c_int, [c_void_p, C.POINTER(ARState), c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "valle_entropix_metrics": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "valle_logsoftmax_colsum": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "valle_entropix_pick": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_void_p, c_int, c_void_p, c_int, C.c_uint64, C.c_uint64, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_void_p]),
     "valle_decode_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "valle_ar_decode": (c_int, [c_void_p, C.POINTER(ARState), C.POINTER(SampleParams), c_int, c_void_p, c_int,
                                 c_void_p, c_size_t, c_void_p]),

@@ -144,6 +144,13 @@ int valle_attn_decode_bf16(const void* q, size_t q_row_stride, const void* kcach
                            const int32_t* ctx_len, const int32_t* cache_slot, void* out, int B, int H, int cache_T,
                            int ctx_extra, int out_frag, hipStream_t s);
 
+// raw scaled attention products of chosen rows (entropix.hip): [rows][H][ld] fp32, see attn_row_scores_kernel
+int valle_attn_row_scores_dense(const void* qkv, int d, const int32_t* rows, int n_rows, const int32_t* cu, int B, int H,
+                                float* out, int ld, int dtype, hipStream_t s);
+int valle_attn_row_scores_cache(const void* q, size_t q_row_stride, const void* kcache, const int32_t* ctx_len,
+                                const int32_t* slot, int ctx_extra, int B, int H, int cache_T, float* out, int ld, int dtype,
+                                hipStream_t s);
+
 // attention launchers (ops_basic.hip)
 extern "C" int valle_attn_prefill_rowwise(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int M,
                                           int H, int Dh, int causal, int dtype, void* stream);

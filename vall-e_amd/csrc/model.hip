@@ -157,12 +157,13 @@ extern "C" size_t valle_dense_workspace_bytes(const valle_model* m, int M, int n
     return t;
 }
 
-extern "C" int valle_forward_dense(valle_model* m, const int32_t* emb_idx, const int32_t* pos,
-                                   const int32_t* cu_seqlens, int B, int M, int max_T, int causal,
-                                   void* kcache, void* vcache, int cache_T, size_t cache_layer_stride,
-                                   const int32_t* cache_slot, const int32_t* cache_pos0,
-                                   const int32_t* out_rows, int n_out, int head, float* logits, int ld_logits,
-                                   void* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
+static int forward_dense_impl(valle_model* m, const int32_t* emb_idx, const int32_t* pos,
+                              const int32_t* cu_seqlens, int B, int M, int max_T, int causal,
+                              void* kcache, void* vcache, int cache_T, size_t cache_layer_stride,
+                              const int32_t* cache_slot, const int32_t* cache_pos0,
+                              const int32_t* out_rows, int n_out, int head, float* logits, int ld_logits,
+                              void* hidden_out, void* workspace, size_t workspace_bytes, void* stream,
+                              const int32_t* score_rows, int n_score, float* scores, int ld_scores) {
     VALLE_REQUIRE(m && emb_idx && pos && cu_seqlens && workspace, VALLE_E_ARG, "valle_forward_dense: null pointer");
     VALLE_REQUIRE(B > 0 && M > 0, VALLE_E_ARG, "valle_forward_dense: empty batch (B=%d, M=%d)", B, M);
     VALLE_REQUIRE(n_out == 0 || out_rows, VALLE_E_ARG, "valle_forward_dense: out_rows missing");
@@ -202,6 +203,8 @@ extern "C" int valle_forward_dense(valle_model* m, const int32_t* emb_idx, const
             else RUN(valle_gemm(h, w.w_qkv, nullptr, nullptr, qkv, M, 3 * d, d, 3 * d, VALLE_EPI_STORE, dt, s));
             RUN(valle_rope_kv(qkv, pos, m->rope, cu_seqlens, B, M, H, Dh, kc, vc, cache_T, cache_slot, cache_pos0, dt, s));
         }
+        if (scores && l == c.n_layers - 1)      // output_attentions: the last layer's raw scaled products of the chosen rows
+            RUN(valle_attn_row_scores_dense(qkv, d, score_rows, n_score, cu_seqlens, B, H, scores, ld_scores, dt, s));
         RUN(valle_attn_prefill(qkv, h, cu_seqlens, B, M, max_T, H, Dh, causal, dt, s));
         // Behind the last layer's attention only the rows the caller asked for are read again (the other rows' K/V have
         // been consumed): output projection and MLP of the last layer run on those rows alone -- the same arithmetic per
@@ -237,6 +240,32 @@ extern "C" int valle_forward_dense(valle_model* m, const int32_t* emb_idx, const
     return VALLE_OK;
 }
 
+extern "C" int valle_forward_dense(valle_model* m, const int32_t* emb_idx, const int32_t* pos,
+                                   const int32_t* cu_seqlens, int B, int M, int max_T, int causal,
+                                   void* kcache, void* vcache, int cache_T, size_t cache_layer_stride,
+                                   const int32_t* cache_slot, const int32_t* cache_pos0,
+                                   const int32_t* out_rows, int n_out, int head, float* logits, int ld_logits,
+                                   void* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return forward_dense_impl(m, emb_idx, pos, cu_seqlens, B, M, max_T, causal, kcache, vcache, cache_T, cache_layer_stride,
+                              cache_slot, cache_pos0, out_rows, n_out, head, logits, ld_logits, hidden_out, workspace,
+                              workspace_bytes, stream, nullptr, 0, nullptr, 0);
+}
+
+extern "C" int valle_forward_dense_scores(valle_model* m, const int32_t* emb_idx, const int32_t* pos,
+                                          const int32_t* cu_seqlens, int B, int M, int max_T, int causal,
+                                          void* kcache, void* vcache, int cache_T, size_t cache_layer_stride,
+                                          const int32_t* cache_slot, const int32_t* cache_pos0,
+                                          const int32_t* out_rows, int n_out, int head, float* logits, int ld_logits,
+                                          void* hidden_out, void* workspace, size_t workspace_bytes, void* stream,
+                                          const int32_t* score_rows, int n_score, float* scores, int ld_scores) {
+    VALLE_REQUIRE(score_rows && scores && n_score > 0, VALLE_E_ARG, "valle_forward_dense_scores: score rows / buffer missing");
+    VALLE_REQUIRE(ld_scores >= max_T, VALLE_E_ARG, "valle_forward_dense_scores: ld_scores %d < max_T %d", ld_scores, max_T);
+    VALLE_REQUIRE(m && m->cfg.d_model / m->cfg.n_heads == 64, VALLE_E_UNSUPPORTED, "valle_forward_dense_scores: head_dim 64 only");
+    return forward_dense_impl(m, emb_idx, pos, cu_seqlens, B, M, max_T, causal, kcache, vcache, cache_T, cache_layer_stride,
+                              cache_slot, cache_pos0, out_rows, n_out, head, logits, ld_logits, hidden_out, workspace,
+                              workspace_bytes, stream, score_rows, n_score, scores, ld_scores);
+}
+
 extern "C" size_t valle_decode_workspace_bytes(const valle_model* m, int B) {
     const size_t es = dtype_size(m->cfg.dtype), d = m->cfg.d_model, f = m->cfg.d_ff;
     size_t t = 0;
@@ -252,7 +281,8 @@ extern "C" size_t valle_decode_workspace_bytes(const valle_model* m, int B) {
 
 static int ar_decode_impl(valle_model* m, const valle_ar_state* st, const valle_sample_params* sp,
                           int n_steps, float* logits_out, int ld_logits,
-                          void* workspace, size_t workspace_bytes, void* stream) {
+                          void* workspace, size_t workspace_bytes, void* stream,
+                          float* scores = nullptr, int ld_scores = 0) {
     VALLE_REQUIRE(m && st && workspace, VALLE_E_ARG, "valle_ar_decode: null pointer");
     VALLE_REQUIRE(sp != nullptr || n_steps == 1, VALLE_E_ARG, "valle_ar_decode: without sampler params only one step can run");
     VALLE_REQUIRE(n_steps >= 1, VALLE_E_ARG, "valle_ar_decode: n_steps %d", n_steps);
@@ -316,6 +346,8 @@ static int ar_decode_impl(valle_model* m, const valle_ar_state* st, const valle_
                 a.rope_m = rope_m; a.ctx_len = st->ctx_len; a.slot = st->cache_slot;
                 a.kc = (bf16*)kc; a.vc = (bf16*)vc; a.cache_T = st->cache_T; a.H = H; a.d = d;
                 RUN(valle_dec_wave_linear(a, DEC_EPI_QKV, s));
+                if (scores && l == c.n_layers - 1)
+                    RUN(valle_attn_row_scores_cache(qkv, (size_t)3 * d, kc, st->ctx_len, st->cache_slot, 1, B, H, st->cache_T, scores, ld_scores, dt, s));
                 RUN(valle_attn_decode_bf16(qkv, (size_t)3 * d, kc, vc, st->ctx_len, st->cache_slot, attf, B, H, st->cache_T, 1, 1, s));
                 DecWArgs o{};
                 o.x = attf; o.W = (const bf16*)w.p_o; o.resid = xf; o.out = xf; o.B = B; o.N = d; o.K = d;
@@ -331,6 +363,8 @@ static int ar_decode_impl(valle_model* m, const valle_ar_state* st, const valle_
                 RUN(valle_rmsnorm(x, w.ln1, h, B, d, c.rms_eps, dt, s));
                 RUN(valle_gemm(h, w.w_qkv, nullptr, nullptr, qkv, B, 3 * d, d, 3 * d, VALLE_EPI_STORE, dt, s));
                 RUN(valle_rope_kv(qkv, pos, m->rope, cu, B, B, H, Dh, kc, vc, st->cache_T, st->cache_slot, st->ctx_len, dt, s));
+                if (scores && l == c.n_layers - 1)
+                    RUN(valle_attn_row_scores_cache(qkv, (size_t)3 * d, kc, st->ctx_len, st->cache_slot, 1, B, H, st->cache_T, scores, ld_scores, dt, s));
                 RUN(valle_attn_decode_launch(qkv, kc, vc, st->ctx_len, st->cache_slot, att, B, H, Dh, st->cache_T, 1, dt, s));
                 RUN(valle_gemm(att, w.w_o, nullptr, x, x, B, d, d, d, VALLE_EPI_RESID, dt, s));
                 RUN(valle_rmsnorm(x, w.ln2, h, B, d, c.rms_eps, dt, s));
@@ -367,6 +401,14 @@ extern "C" int valle_ar_decode(valle_model* m, const valle_ar_state* st, const v
                                int n_steps, float* logits_out, int ld_logits,
                                void* workspace, size_t workspace_bytes, void* stream) {
     return ar_decode_impl(m, st, sp, n_steps, logits_out, ld_logits, workspace, workspace_bytes, stream);
+}
+
+extern "C" int valle_ar_decode_scores(valle_model* m, const valle_ar_state* st, float* logits_out, int ld_logits,
+                                      float* scores, int ld_scores, void* workspace, size_t workspace_bytes, void* stream) {
+    VALLE_REQUIRE(logits_out && scores, VALLE_E_ARG, "valle_ar_decode_scores: logits / scores buffer missing");
+    VALLE_REQUIRE(st && ld_scores >= st->max_ctx + 1, VALLE_E_ARG, "valle_ar_decode_scores: ld_scores too small for max_ctx + 1 keys");
+    VALLE_REQUIRE(m && m->cfg.d_model / m->cfg.n_heads == 64, VALLE_E_UNSUPPORTED, "valle_ar_decode_scores: head_dim 64 only");
+    return ar_decode_impl(m, st, nullptr, 1, logits_out, ld_logits, workspace, workspace_bytes, stream, scores, ld_scores);
 }
 
 // ------------------------------------------------------------------ decode without a caller workspace

@@ -47,23 +47,32 @@ class AR_NAR(Base):
         """Base.forward on an explicit batch description -- all rows' logits.  ``inputs`` is either what
         ``self.inputs(...)`` returns (the reference's list of (name, value) tuples per utterance, ar_nar.py:36-37)
         or a dict with the keyword lists of ``plan`` (phns_list, lang_list, proms_list, resps_list)."""
-        if output_attentions or output_hidden_states or state is not None:
-            raise NotImplementedError("attentions / hidden states / external state are not exposed")
+        if output_hidden_states or state is not None:
+            raise NotImplementedError("hidden states / external state are not exposed")
         if isinstance(inputs, (list, tuple)):
             plan = self.plan_from_inputs(inputs)
-            rows, off = self.tail_rows(plan, plan.lens)
-            lg = self.forward_dense(plan, rows)
-            V = self.cls_tokens[plan.head]
-            return Logits([lg[off[i]:off[i + 1], :V] for i in range(plan.B)], None, inputs, None, None, None)
-        q = 0 if quant_levels is None else int(quant_levels[0])
-        if quant_levels is not None and any(int(x) != q for x in quant_levels):
-            raise NotImplementedError("one quant level per batch")
-        plan = self.plan(inputs.get("phns_list"), inputs.get("lang_list"), inputs.get("proms_list"),
-                         inputs["resps_list"], q, timestep=inputs.get("timestep", False))
+        else:
+            q = 0 if quant_levels is None else int(quant_levels[0])
+            if quant_levels is not None and any(int(x) != q for x in quant_levels):
+                raise NotImplementedError("one quant level per batch")
+            plan = self.plan(inputs.get("phns_list"), inputs.get("lang_list"), inputs.get("proms_list"),
+                             inputs["resps_list"], q, timestep=inputs.get("timestep", False))
         rows, off = self.tail_rows(plan, plan.lens)
-        lg = self.forward_dense(plan, rows)
         V = self.cls_tokens[plan.head]
-        return Logits([lg[off[i]:off[i + 1], :V] for i in range(plan.B)], None, inputs, None, None, None)
+        attentions = None
+        if output_attentions:
+            # the reference returns every layer's (B, H, T, T) raw scaled products (arch/llama.py:429, :469-477); here the LAST
+            # layer's only -- the one its consumer reads (samplers.py:294) -- as a one-element list, zero-padded like the
+            # reference's right-padded batch
+            lg, sc = self.forward_dense(plan, rows, score_rows=rows)
+            att = torch.zeros((plan.B, self.n_heads, plan.max_T, plan.max_T), dtype=torch.float32, device=self.device)
+            for i in range(plan.B):
+                n = int(plan.lens[i])
+                att[i, :, :n, :n] = sc[off[i]:off[i + 1], :, :n].transpose(0, 1)
+            attentions = [att]
+        else:
+            lg = self.forward_dense(plan, rows)
+        return Logits([lg[off[i]:off[i + 1], :V] for i in range(plan.B)], None, inputs, None, attentions, None)
 
     # ------------------------------------------------------------------------------ dispatch
     def forward(self, task_list=None, phns_list=None, proms_list=None, resps_list=None, lang_list=None, tone_list=None,
@@ -169,7 +178,12 @@ class AR_NAR(Base):
         input_prompt_prefix = kw.pop("input_prompt_prefix", False)
         refine_on_stop = kw.pop("refine_on_stop", False)
         prefix_silence = kw.pop("prefix_silence", 0.0)
+        entropix = bool(kw.pop("entropix_sampling", False))                   # ar_nar.py:782, :807
+        entropix_noise = kw.pop("entropix_noise", None)                       # tests: [step] -> (B, 5, n) Exponential(1) variates
+        trace = kw.pop("trace", None)                                         # list: receives every step's metrics dicts
         beam_width = int(kw.pop("beam_width", 0) or 0)
+        if entropix and (beam_width > 1 or kw.get("cfg_strength", 0.0) > 0 or refine_on_stop or return_logits):
+            raise NotImplementedError("entropix sampling together with beam search / guidance / refine_on_stop / return_logits")
         if beam_width == 1:
             beam_width = 0          # base.py:1412 needs > 1; a beam of one is plain sampling (the scores it keeps are unused)
         if beam_width > 1:
@@ -229,6 +243,9 @@ class AR_NAR(Base):
         # behind the prompt reads its neighbour's id and the LAST row -- the newest token -- always gets 1, so a token's
         # position changes from one step to the next.  A KV cache holds keys rotated once; these calls therefore recompute
         # the sequence every step, as the reference does (measured: cache-path logits off by 1e-2 on the tiny model).
+        if entropix:
+            return self._ar_entropix(phns_list, proms_list, lang_list, prefix, prefix_lens, prefix_context, start_slice, n_steps,
+                                     seq, seq_len, stopped, scores, cap, kw, entropix_noise, trace)
         if not self.unified_position_ids and proms_list is not None and any(
                 isinstance(p, (list, tuple)) and any(isinstance(x, str) for x in p) for p in proms_list):
             all_logits = self._ar_recompute(passes, lang_list, prefix, n_steps, seq, seq_len, stopped, scores, sp, cap,
@@ -353,6 +370,68 @@ class AR_NAR(Base):
                     break
         return self._ar_finish(seq, seq_len, prefix, prefix_lens, prefix_context, start_slice, refine_on_stop, n_steps,
                                phns_list, lang_list, proms_list, return_logits, all_logits)
+
+    def _ar_entropix(self, phns_list, proms_list, lang_list, prefix, prefix_lens, prefix_context, start_slice, n_steps,
+                     seq, seq_len, stopped, scores, cap, kw, noise, trace):
+        """The AR loop under entropix_sampling (ar_nar.py:778-783, :804-808 -> base.py:1325-1342 -> samplers.py:464-566): every
+        step hands the whole sequence's logits and the last layer's raw attention products of the newest row to
+        sample_entropix, and nothing else of the sampler chain runs.  Host-driven, one small device->host copy per step
+        (the reference does this part on the CPU altogether).  Kept on the device: the KV cache, the running column sums of
+        log_softmax over all rows so far (the adaptive branch's ranking, samplers.py:527-545), the sequences."""
+        lib = L.load()
+        B, dev = len(phns_list), self.device
+        if proms_list is not None and not self.unified_position_ids and any(
+                isinstance(p, (list, tuple)) and any(isinstance(x, str) for x in p) for p in proms_list):
+            raise NotImplementedError("entropix sampling with task tokens in the prompt (their position ids move per step)")
+        V = self.cls_tokens[0]
+        ld = _round_up(V, 8)
+        H, Dh, Lyr = self.n_heads, self.d_model // self.n_heads, self.n_layers
+        slot = torch.arange(B, dtype=torch.int32, device=dev)
+        plan = self.plan(phns_list, lang_list, proms_list, [torch.from_numpy(p) for p in prefix], 0)
+        if plan.max_T + n_steps + 1 > self.max_position_embeddings:
+            raise ValueError(f"sequence of {plan.max_T} + {n_steps} steps exceeds max_position_embeddings ({self.max_position_embeddings})")
+        cache_T = _round_up(plan.max_T + n_steps + 1, 8)
+        stride = B * H * cache_T * Dh
+        kc = torch.empty((Lyr, B, H, cache_T, Dh), dtype=self.dtype, device=dev)
+        vc = torch.empty_like(kc)
+        rows, off = self.tail_rows(plan, plan.lens)                          # every row: the ranking sums over all of them
+        last_rows = (plan.cu[1:] - 1).astype(np.int32)
+        pos0 = torch.zeros(B, dtype=torch.int32, device=dev)
+        lg, sc = self.forward_dense(plan, rows, cache=(kc, vc, cache_T, stride, slot, pos0), score_rows=last_rows)
+        ctx_len = self._i32(plan.lens)
+        resp_pos0 = self._i32([plan.lens[i] - len(prefix[i]) if self.unified_position_ids else 0 for i in range(B)])
+        st = L.ARState(B, cap, seq.data_ptr(), seq_len.data_ptr(), ctx_len.data_ptr(), resp_pos0.data_ptr(), slot.data_ptr(),
+                       stopped.data_ptr(), scores.data_ptr(), kc.data_ptr(), vc.data_ptr(), cache_T, stride, self._off["resp0"],
+                       0, V, 0, int(plan.max_T))
+        ws = torch.empty(lib.valle_decode_workspace_bytes(self._handle, B), dtype=torch.uint8, device=dev)
+        stream = L.stream_ptr(dev)
+        colsum = torch.empty((B, ld), dtype=torch.float32, device=dev)
+        off_d = self._i32(off)
+        L.check(lib.valle_logsoftmax_colsum(L.ptr(lg), ld, V, L.ptr(off_d), B, L.ptr(colsum), ld, 0, stream))
+        step_off = self._i32(np.arange(B + 1))
+        greedy = self.sample_params(temperature=0.0, top_no=0.0)
+        kws = dict(temperature=kw.get("temperature", 1.0), top_k=kw.get("top_k", -100), top_p=kw.get("top_p", 1.0), seed=kw.get("seed", 0))
+        step_lg = torch.empty((B, ld), dtype=torch.float32, device=dev)
+        step_sc = torch.zeros((B, H, cache_T), dtype=torch.float32, device=dev)
+        for step in range(n_steps):
+            if step == 0:
+                cur, cur_rows, cur_sc = lg, last_rows, sc
+            else:
+                st.max_ctx = int(plan.max_T) + step - 1
+                L.check(lib.valle_ar_decode_scores(self._handle, C.byref(st), L.ptr(step_lg), ld, L.ptr(step_sc), cache_T,
+                                                   L.ptr(ws), ws.numel(), stream))
+                L.check(lib.valle_logsoftmax_colsum(L.ptr(step_lg), ld, V, L.ptr(step_off), B, L.ptr(colsum), ld, 1, stream))
+                cur, cur_rows, cur_sc = step_lg, None, step_sc
+            ids, metrics, forced = self.entropix_sample(cur, cur_rows, V, cur_sc, [int(n) + step for n in plan.lens], colsum,
+                                                        offset=step, noise=None if noise is None else noise[step],
+                                                        want_forced=True, **kws)
+            if trace is not None:
+                trace.append(metrics)
+            self._ar_sample_append(forced, V, seq, seq_len, [ctx_len], stopped, scores, greedy, cap, step=step, bump_ctx=step > 0)
+            if bool(stopped.all().item()):
+                break
+        return self._ar_finish(seq, seq_len, prefix, prefix_lens, prefix_context, start_slice, False, n_steps,
+                               phns_list, lang_list, proms_list, False, [])
 
     def _ar_finish(self, seq, seq_len, prefix, prefix_lens, prefix_context, start_slice, refine_on_stop, n_steps,
                    phns_list, lang_list, proms_list, return_logits, all_logits):

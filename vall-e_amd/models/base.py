@@ -25,7 +25,7 @@ Sampled = namedtuple("Sampled", ["ids", "logits", "scores", "entropy"])         
 # mirostat_tau / mirostat_eta are accepted and change nothing, as in the reference: forward_ar builds the mirostat
 # state list (ar_nar.py:702-704) but its Base.sample call (:804-808) never passes ``mirostat=``, so basic sampling
 # runs (golden tiny_mirostat_tau).  Only a caller-made ``mirostat=[state, ...]`` kwarg reaches samplers.py:197-238.
-UNSUPPORTED_SAMPLERS = ("beam_width", "entropix_sampling", "layer_skip")
+UNSUPPORTED_SAMPLERS = ("beam_width", "layer_skip")
 
 
 # data.py:670-688 (get_task_symmap): rows of tasks_emb
@@ -531,7 +531,7 @@ class Base:
         """Device copies of a plan's integer tables: (idx [M][8], pos [M], cu [B+1], rows [n_out])."""
         return tuple(self._upload_i32(plan.idx, plan.pos, plan.cu, out_rows))
 
-    def forward_dense(self, plan: Plan, out_rows, *, cache=None, want_hidden=False, dev=None):
+    def forward_dense(self, plan: Plan, out_rows, *, cache=None, want_hidden=False, dev=None, score_rows=None):
         """Runs the stack on a packed plan; returns fp32 logits (n_out, ld) for the packed row ids
         in ``out_rows`` (head = plan.head).  cache = (k, v, cache_T, layer_stride, slot, pos0);
         dev = upload_plan(...) made earlier (possibly patched on the device since)."""
@@ -555,6 +555,17 @@ class Base:
             cache_T, stride = 0, 0
         else:
             kc, vc, cache_T, stride, slot, pos0 = cache
+        if score_rows is not None:
+            # output_attentions: also the last layer's raw attention products of the packed rows in score_rows, over every
+            # key of their utterance -> (n_score, H, max_T) fp32 (valle_forward_dense_scores)
+            srows = self._i32(score_rows)
+            scores = torch.zeros((len(score_rows), self.n_heads, plan.max_T), dtype=torch.float32, device=self.device)
+            L.check(lib.valle_forward_dense_scores(self._handle, L.ptr(idx), L.ptr(pos), L.ptr(cu), plan.B, plan.M, plan.max_T, causal,
+                                                   L.ptr(kc), L.ptr(vc), cache_T, stride, L.ptr(slot), L.ptr(pos0),
+                                                   L.ptr(rows), n_out, plan.head, L.ptr(logits), ld, L.ptr(hidden),
+                                                   L.ptr(ws), ws.numel(), L.stream_ptr(self.device),
+                                                   L.ptr(srows), len(score_rows), L.ptr(scores), plan.max_T))
+            return (logits, hidden, scores) if want_hidden else (logits, scores)
         L.check(lib.valle_forward_dense(self._handle, L.ptr(idx), L.ptr(pos), L.ptr(cu), plan.B, plan.M, plan.max_T, causal,
                                         L.ptr(kc), L.ptr(vc), cache_T, stride, L.ptr(slot), L.ptr(pos0),
                                         L.ptr(rows), n_out, plan.head, L.ptr(logits), ld, L.ptr(hidden),
@@ -585,8 +596,9 @@ class Base:
         if other.get("mirostat") is not None:
             raise NotImplementedError("an explicit mirostat state list goes through Base.sample (not the generation loops, "
                                       "which never pass one in the reference either: ar_nar.py:804-808)")
-        if other.get("attentions") is not None:
-            raise NotImplementedError("entropix sampling is not built on the HIP path")
+        if other.get("attentions") is not None or other.get("entropix_sampling"):
+            raise NotImplementedError("entropix sampling runs through forward_ar(entropix_sampling=True) / Base.sample(attentions=...), "
+                                      "not through the processor chain (the reference returns before it, base.py:1327-1342)")
         if min_temperature < 0:
             min_temperature = temperature
         if abs(float(temperature) - float(min_temperature)) < 0.001:          # base.py:1389: dynamic temperature off
@@ -597,12 +609,123 @@ class Base:
                               float(temperature), float(min_temperature), float(dry_multiplier), float(dry_base),
                               int(dry_allowed_length), int(filter_passes))
 
+    # ------------------------------------------------------------------------------ entropix
+    # samplers.py:364-414 (EntropixSamplerConfig)
+    ENTROPIX = dict(
+        min_p=0.01, low_ent_thresh=0.1, low_vent_thresh=0.1, med_ent_thresh=3.0, high_ent_thresh=5.0, high_vent_thresh=5.0,
+        helv_attn_ent_offset=1.3, helv_attn_ent_coef=0.2, lehv_interaction_strength_offset=1.2,
+        lehv_interaction_strength_coef=0.3, hehv_attn_ent_coef=0.2, hehv_attn_vent_offset=2.0, hehv_attn_vent_coef=0.5,
+        n_adaptive_samples=5, ada_temp_logits=0.3, ada_temp_attn=0.2, ada_temp_agree=0.2, ada_top_p=0.1, ada_top_k_int=0.3,
+        ada_top_k_agree=0.2, ada_min_p=0.5, temperature_max=1.25, temperature_min=0.5, top_k_min=1, top_k_max=1024,
+        top_p_min=0.1, top_p_max=1.0)
+    ENTROPIX_KEYS = ("logits_entropy", "logits_varentropy", "attn_entropy", "attn_varentropy", "agreement", "interaction_strength")
+
+    @classmethod
+    def entropix_branch(cls, m, temperature, top_k, top_p, vocab):
+        """The branch arithmetic of sample_entropix (samplers.py:489-523) and the clamps of _sample_entropix (:428-436) on one
+        utterance's metrics (Python floats, as in the reference) -> (action, temperature, top_k, top_p, draws).  Branch 0
+        raises the IndexError the reference dies of there (``logits[-1, :].argmax(dim=1)`` on a 1-D row, :492)."""
+        C_ = cls.ENTROPIX
+        ent, vent = m["logits_entropy"], m["logits_varentropy"]
+        a_ent, a_vent, agree, inter = m["attn_entropy"], m["attn_varentropy"], m["agreement"], m["interaction_strength"]
+        draws = 1
+        if ent < C_["low_ent_thresh"] and vent < C_["low_vent_thresh"]:
+            raise IndexError("Dimension out of range (expected to be in range of [-1, 0], but got 1)")
+        elif ent > C_["high_ent_thresh"] and vent < C_["low_vent_thresh"]:
+            action = 1
+            temperature *= C_["helv_attn_ent_offset"] + C_["helv_attn_ent_coef"] * a_ent
+        elif ent < C_["high_ent_thresh"] and vent > C_["high_vent_thresh"]:
+            action = 2
+            temperature *= C_["lehv_interaction_strength_offset"] + C_["lehv_interaction_strength_coef"] * inter
+            top_k = max(5, int(top_k * (1 + 0.5 * (1 - agree))))
+        elif ent > C_["med_ent_thresh"] and vent > C_["high_vent_thresh"]:
+            action = 3
+            temperature *= C_["hehv_attn_vent_offset"] + C_["hehv_attn_vent_coef"] * a_vent
+            top_p = max(0.5, top_p - C_["hehv_attn_ent_coef"] * a_ent)
+        else:
+            action = 4
+            lu, au = ent + vent, a_ent + a_vent
+            temperature *= 1 + C_["ada_temp_logits"] * lu + C_["ada_temp_attn"] * au - C_["ada_temp_agree"] * agree
+            top_p = top_p * (1 + C_["ada_top_p"] * a_vent)
+            top_k = round(float(top_k * (1 + C_["ada_top_k_int"] * inter - C_["ada_top_k_agree"] * agree)))
+            draws = C_["n_adaptive_samples"]
+        if top_k == 0:
+            top_k = vocab
+        clamp = lambda n, lo, hi: max(lo, min(n, hi))
+        return (action, clamp(float(temperature), C_["temperature_min"], C_["temperature_max"]),
+                clamp(int(top_k), C_["top_k_min"], C_["top_k_max"]), clamp(float(top_p), C_["top_p_min"], C_["top_p_max"]), draws)
+
+    def entropix_sample(self, logits, logit_row, vocab, scores, n_keys, colsum, *, temperature=1.0, top_k=-100, top_p=1.0,
+                        seed=0, offset=0, noise=None, want_forced=False):
+        """sample_entropix (samplers.py:464-566) for B utterances on the device: metrics of logits row logit_row[b] and
+        scores[b] (H, ld) over n_keys[b] keys (valle_entropix_metrics), the branch arithmetic on the host (one small copy --
+        the reference does all of it on the CPU), then the draws (valle_entropix_pick).  colsum (B, ld) = sum over every
+        row of the sequence of log_softmax (what the adaptive branch ranks its draws by).  noise (B, 5, n): the
+        Exponential(1) variates per draw and ascending position (tests); None: the Philox stream of (seed, offset).
+        -> (ids int32 (B,), metrics dicts, forced logits or None)."""
+        lib = L.load()
+        B = len(n_keys)
+        stream = L.stream_ptr(self.device)
+        met = torch.empty((B, 8), dtype=torch.float32, device=self.device)
+        nk = self._i32(n_keys)
+        rows = None if logit_row is None else self._i32(logit_row)
+        L.check(lib.valle_entropix_metrics(L.ptr(logits), logits.shape[1], vocab, L.ptr(rows), L.ptr(scores), scores.shape[2],
+                                           scores.shape[1], L.ptr(nk), B, L.ptr(met), stream))
+        host = met.cpu().numpy()
+        metrics, par = [], []
+        for b in range(B):
+            m = {k: float(host[b, i]) for i, k in enumerate(self.ENTROPIX_KEYS)}
+            action, t, k, p, draws = self.entropix_branch(m, temperature, top_k, top_p, vocab)
+            m["action"] = action
+            metrics.append(m)
+            par.append((t, k, p, draws))
+        f32 = lambda v: self._h2d(np.ascontiguousarray(v, dtype=np.float32))
+        t_d, p_d = f32([x[0] for x in par]), f32([x[2] for x in par])
+        k_d, n_d = self._i32([x[1] for x in par]), self._i32([x[3] for x in par])
+        ids = torch.empty(B, dtype=torch.int32, device=self.device)
+        draws = torch.empty((B, 5), dtype=torch.int32, device=self.device)
+        forced = torch.empty((B, logits.shape[1]), dtype=torch.float32, device=self.device) if want_forced else None
+        if noise is not None:
+            noise = noise.to(self.device, torch.float32).contiguous()
+        L.check(lib.valle_entropix_pick(L.ptr(logits), logits.shape[1], vocab, L.ptr(rows), B, L.ptr(t_d), L.ptr(k_d), L.ptr(p_d),
+                                        L.ptr(n_d), 5, L.ptr(colsum), 0 if colsum is None else colsum.shape[1],
+                                        L.ptr(noise), 0 if noise is None else noise.shape[2], int(seed), int(offset),
+                                        L.ptr(ids), L.ptr(draws), L.ptr(forced), 0 if forced is None else forced.shape[1], stream))
+        return ids, metrics, forced
+
+    def _sample_entropix_call(self, logits, attentions, temperature, top_k, top_p, seed=0, noise=None):
+        """Base.sample(attentions=...) (base.py:1325-1342): ``attentions`` as the reference's forward returns them -- a
+        sequence over layers of (B, H, T, T) raw scaled products, of which the LAST layer's newest row per utterance is read
+        (samplers.py:294, :482) -- or just [last layer], which is what forward_super(output_attentions=True) gives here."""
+        lib = L.load()
+        B = len(logits)
+        V = int(logits[0].shape[-1])
+        lens = [int(l.shape[0]) for l in logits]
+        last = attentions[-1]
+        ld = _round_up(V, 8)
+        flat = torch.zeros((sum(lens), ld), dtype=torch.float32, device=self.device)
+        flat[:, :V] = torch.cat([l.to(self.device, torch.float32) for l in logits])
+        off = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+        scores = torch.zeros((B, last.shape[1], max(lens)), dtype=torch.float32, device=self.device)
+        for b in range(B):
+            scores[b, :, :lens[b]] = last[b, :, lens[b] - 1, :lens[b]].to(self.device, torch.float32)
+        colsum = torch.empty((B, ld), dtype=torch.float32, device=self.device)
+        off_d = self._i32(off)
+        L.check(lib.valle_logsoftmax_colsum(L.ptr(flat), ld, V, L.ptr(off_d), B, L.ptr(colsum), ld, 0, L.stream_ptr(self.device)))
+        ids, metrics, _ = self.entropix_sample(flat, off[1:] - 1, V, scores, lens, colsum, temperature=temperature, top_k=top_k,
+                                               top_p=top_p, seed=seed, noise=noise)
+        return Sampled([ids[b:b + 1].long() for b in range(B)], logits, None, metrics)
+
     def sample(self, logits, prev_list=None, **sampling_kwargs):
         """``Base.sample`` (base.py:1280-1430): logits = list of per-utterance (rows, vocab) tensors; with
         ``prev_list`` of equal row counts the call is a NAR one (all rows sampled), otherwise only the last
         ``causal_size`` row of each utterance is (AR).  -> Sampled(ids, logits, scores, entropy=None)."""
         B = len(logits)
         V = int(logits[0].shape[-1])
+        if sampling_kwargs.get("attentions") is not None and sampling_kwargs.get("quant_levels") is None:   # base.py:1327
+            kw = sampling_kwargs
+            return self._sample_entropix_call(logits, kw["attentions"], kw.get("temperature", 1.0), kw.get("top_k", -100),
+                                              kw.get("top_p", 1.0), seed=kw.get("seed", 0), noise=kw.get("entropix_noise"))
         if prev_list is not None and all(len(p) == l.shape[0] for p, l in zip(prev_list, logits)):
             nar, rows = 1, logits
         else:
