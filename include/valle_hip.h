@@ -352,6 +352,20 @@ int valle_ar_decode(valle_model* m, const valle_ar_state* st, const valle_sample
                     int n_steps, float* logits_out, int ld_logits,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* n_steps steps of the classifier-free-guidance AR loop (models/ar_nar.py:785-808) with no host round trip: per step, one
+ * logits-only decode step on the conditional state and one on the null state (they share seq / seq_len / stopped and
+ * differ in the caches, resp_pos0 and ctx_len), whose logits land in row hist_row0 + step of every utterance's
+ * [hist_rows][ld] block of hist_pos / hist_neg; valle_cfg_combine_last over rows [row_start[b], row_start[b] +
+ * row_count0[b] + step) -> last + i * last_step_stride ([B][ld]; stride 0 reuses one buffer); valle_sample_append with sp
+ * (Philox offset sp->offset + i) bumping both ctx_len.  first_step >= 1 is the index of the first of these steps in the
+ * whole loop (step 0 samples from the prefill's rows, host side).  The caller checks `stopped` between calls. */
+int valle_ar_decode_cfg(valle_model* m, const valle_ar_state* st_pos, const valle_ar_state* st_neg,
+                        const valle_sample_params* sp, int n_steps, int first_step,
+                        float* hist_pos, float* hist_neg, int ld, int hist_rows, int hist_row0,
+                        const int32_t* row_start, const int32_t* row_count0, float strength, float rescale,
+                        float* last, size_t last_step_stride,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* One logits-only decode step (valle_ar_decode with sp == NULL, n_steps 1) that also returns the last layer's raw attention
  * products of every utterance's newest row against its ctx_len[b] + 1 cached keys: scores [B][H][ld_scores] fp32,
  * ld_scores >= max_ctx + 1 (same values as valle_forward_dense_scores gives for that row of a recompute).

@@ -1260,7 +1260,7 @@ def test_narlen_b64_properties(gpu_device):
     2.5 / 0.75, bf16 -- what tools/time_configs.py times.  No mask token survives, codes are in range, the run is
     reproducible, and utterance i of the batch equals the same utterance run alone (batch independence: the packed layout
     must not leak across utterances).  The solo run's GEMMs take other tiles (M = 761 against ~48,000 rows) and 25 rounds
-    of score cuts amplify bf16 near ties: measured agreement 0.97-1.0 per level-0 frame; asked: >= 0.93 (chance: 0.001)."""
+    of score cuts could amplify bf16 near ties: measured agreement 1.0 / 1.0 per level-0 frame; asked: >= 0.97 (chance: 0.001)."""
     from vall_e_amd.synth import synth_batch
     B, R = 64, 450
     phns, proms, langs = synth_batch(99, B, n_phn=80, n_prom=225, ragged=True)
@@ -1278,7 +1278,7 @@ def test_narlen_b64_properties(gpu_device):
         solo = m(task_list=["tts"], phns_list=phns[i:i + 1], proms_list=proms[i:i + 1], lang_list=langs[i:i + 1], len_list=[R], **kw)
         agree.append((solo[0][:, 0] == out[i][:, 0]).float().mean().item())
     print(f"NAR-len B=64 x 450 x 25 bf16: level-0 agreement of utterances 5 / 40 with their solo runs {agree}")
-    assert min(agree) > 0.93, agree
+    assert min(agree) > 0.97, agree
 
 
 @pytest.mark.parametrize("cache_T,ctx", [(96, [1, 7, 96]), (512, [512, 65, 300]), (1024, [1000, 3, 769, 768]), (2600, [2561, 1537, 40]),

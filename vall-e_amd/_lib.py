@@ -97,6 +97,9 @@ SIGNATURES = {
                                            c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p,
                                            c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p,
                                            c_void_p, c_int, c_void_p, c_int]),
+    "valle_ar_decode_cfg": (c_int, [c_void_p, C.POINTER(ARState), C.POINTER(ARState), C.POINTER(SampleParams), c_int, c_int,
+                                    c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float,
+                                    c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
     "valle_ar_decode_scores": (c_int, [c_void_p, C.POINTER(ARState), c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "valle_entropix_metrics": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "valle_logsoftmax_colsum": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),

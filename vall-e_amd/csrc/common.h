@@ -101,6 +101,9 @@ struct SampleArgs {
     const float* nx_rope_tab; float* nx_rope;   // RoPE table [P][64] -> the new position's row, [32][64]
 };
 int valle_sample_launch(const SampleArgs& a, int rows, hipStream_t s);
+int valle_cfg_combine_last_add(const float* pos, const float* neg, int ld, int vocab, const int32_t* row_start,
+                               const int32_t* row_count, int count_add, int B, float strength, float rescale, float* out,
+                               int ld_out, hipStream_t s);
 
 // dense QKV projection with RoPE applied in the epilogue (gemm.hip; internal epilogue code, bf16, head_dim 64):
 // qkv[m][0:2d] rotated by position pos[m] exactly as valle_rope_kv does, qkv[m][2d:3d] stored as is

@@ -411,6 +411,47 @@ extern "C" int valle_ar_decode_scores(valle_model* m, const valle_ar_state* st, 
     return ar_decode_impl(m, st, nullptr, 1, logits_out, ld_logits, workspace, workspace_bytes, stream, scores, ld_scores);
 }
 
+// ------------------------------------------------------------------ guided AR steps without a host round trip
+extern "C" int valle_ar_decode_cfg(valle_model* m, const valle_ar_state* st_pos, const valle_ar_state* st_neg,
+                                   const valle_sample_params* sp, int n_steps, int first_step,
+                                   float* hist_pos, float* hist_neg, int ld, int hist_rows, int hist_row0,
+                                   const int32_t* row_start, const int32_t* row_count0, float strength, float rescale,
+                                   float* last, size_t last_step_stride,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    VALLE_REQUIRE(m && st_pos && st_neg && sp && hist_pos && hist_neg && row_start && row_count0 && last && workspace, VALLE_E_ARG,
+                  "valle_ar_decode_cfg: null pointer");
+    VALLE_REQUIRE(n_steps >= 1 && first_step >= 1, VALLE_E_ARG, "valle_ar_decode_cfg: n_steps %d, first_step %d (step 0 samples from the prefill)", n_steps, first_step);
+    VALLE_REQUIRE(st_pos->B == st_neg->B && st_pos->seq == st_neg->seq && st_pos->seq_len == st_neg->seq_len &&
+                  st_pos->stopped == st_neg->stopped && st_pos->vocab == st_neg->vocab, VALLE_E_ARG,
+                  "valle_ar_decode_cfg: the two states must share the sequences and differ in the caches only");
+    VALLE_REQUIRE(ld >= st_pos->vocab && hist_row0 + first_step + n_steps <= hist_rows, VALLE_E_ARG,
+                  "valle_ar_decode_cfg: history of %d rows too short for rows %d + %d + %d", hist_rows, hist_row0, first_step, n_steps);
+    const int B = st_pos->B;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    for (int i = 0; i < n_steps; ++i) {
+        const int g = first_step + i;                                   // the step's index in the whole loop
+        valle_ar_state a = *st_pos, b = *st_neg;
+        a.max_ctx += i; b.max_ctx += i; a.early_exit = 0; b.early_exit = 0;
+        // the step's logits land in their history rows: row (hist_row0 + g) of every utterance's [hist_rows][ld] block
+        const size_t off = (size_t)(hist_row0 + g) * ld;
+        RUN(ar_decode_impl(m, &a, nullptr, 1, hist_pos + off, hist_rows * ld, workspace, workspace_bytes, stream));
+        RUN(ar_decode_impl(m, &b, nullptr, 1, hist_neg + off, hist_rows * ld, workspace, workspace_bytes, stream));
+        float* out = last + (size_t)i * last_step_stride;
+        // guidance over every response row so far (samplers.py:177-191: the statistics run over rows x vocab), last row out
+        RUN(valle_cfg_combine_last_add(hist_pos, hist_neg, ld, st_pos->vocab, row_start, row_count0, g, B, strength, rescale, out, ld, s));
+        SampleArgs sa{};
+        sa.logits = out; sa.ld = ld; sa.vocab = st_pos->vocab; sa.nar_mode = 0; sa.p = *sp;
+        sa.ids = (int32_t*)workspace;                                   // scratch (the workspace's head is rewritten by the next step's prologue)
+        sa.scores = st_pos->scores;
+        sa.seq = st_pos->seq; sa.seq_cap = st_pos->max_steps; sa.seq_len = st_pos->seq_len; sa.stopped = st_pos->stopped;
+        sa.ctx_len = st_pos->ctx_len; sa.ctx_len2 = st_neg->ctx_len;    // both caches ran the previous token through the stack
+        sa.prev_is_seq = 1; sa.step = (uint64_t)i;
+        RUN(valle_sample_launch(sa, B, s));
+    }
+    return VALLE_OK;
+}
+
 // ------------------------------------------------------------------ decode without a caller workspace
 // valle_ar_decode_noalloc: valle_ar_decode with the step's activations in a static device array instead of a caller
 // workspace, for callers that cannot allocate (HIP graph capture, serving loops that forbid hipMalloc).  Nothing here

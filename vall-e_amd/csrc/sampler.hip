@@ -628,9 +628,9 @@ template <bool LAST>
 __global__ __launch_bounds__(1024) void cfg_combine_kernel(float* __restrict__ pos, const float* __restrict__ neg, int ld,
                                                            int vocab, const int32_t* __restrict__ row_a,
                                                            const int32_t* __restrict__ row_n, float* __restrict__ out_last,
-                                                           int ld_out, float strength, float rescale) {
+                                                           int ld_out, float strength, float rescale, int count_add = 0) {
     const int i = blockIdx.x;
-    const int r0 = row_a[i], r1 = LAST ? r0 + row_n[i] : row_a[i + 1];
+    const int r0 = row_a[i], r1 = LAST ? r0 + row_n[i] + count_add : row_a[i + 1];
     const long n = (long)(r1 - r0) * vocab;
     if (n <= 0) return;
     __shared__ double red[2][16];
@@ -697,6 +697,15 @@ extern "C" int valle_cfg_combine_last(const float* pos, const float* neg, int ld
     VALLE_REQUIRE(vocab > 0 && ld >= vocab && ld_out >= vocab, VALLE_E_ARG, "valle_cfg_combine_last: bad vocab/ld");
     if (B == 0) return VALLE_OK;
     cfg_combine_kernel<true><<<B, 1024, 0, (hipStream_t)stream>>>((float*)pos, neg, ld, vocab, row_start, row_count, out, ld_out, strength, rescale);
+    VALLE_LAUNCH_CHECK();
+    return VALLE_OK;
+}
+
+// (internal: the device-side guidance loop of valle_ar_decode_cfg counts the rows as row_count[i] + count_add)
+int valle_cfg_combine_last_add(const float* pos, const float* neg, int ld, int vocab, const int32_t* row_start,
+                               const int32_t* row_count, int count_add, int B, float strength, float rescale, float* out,
+                               int ld_out, hipStream_t s) {
+    cfg_combine_kernel<true><<<B, 1024, 0, s>>>((float*)pos, neg, ld, vocab, row_start, row_count, out, ld_out, strength, rescale, count_add);
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
 }

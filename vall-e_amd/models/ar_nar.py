@@ -302,7 +302,7 @@ class AR_NAR(Base):
                                             L.ptr(proc), L.ptr(forced), L.ptr(ids), None, stream))
                 self._ar_sample_append(forced, V, seq, seq_len, [states[0][1][2]], stopped, scores, greedy, cap, step=step,
                                        bump_ctx=step > 0)
-                if bool(stopped.all().item()):
+                if bool(stopped.cpu().numpy().all()):
                     break
             out = self._ar_finish(seq, seq_len, prefix, prefix_lens, prefix_context, start_slice, refine_on_stop, n_steps,
                                   phns_list, lang_list, proms_list, return_logits, all_logits)
@@ -315,7 +315,7 @@ class AR_NAR(Base):
             self._ar_sample_append(first_logits[0], V, seq, seq_len, [states[0][1][2]], stopped, scores, sp, cap, step=0)
             done = 1
             while done < n_steps:
-                if bool(stopped.all().item()):                                # ar_nar.py:846 (checked once per chunk)
+                if bool(stopped.cpu().numpy().all()):                                # ar_nar.py:846 (checked once per chunk)
                     break
                 n = min(step_chunk, n_steps - done)
                 lg_out = torch.empty((n, B, ld), dtype=torch.float32, device=dev) if return_logits else None
@@ -349,25 +349,32 @@ class AR_NAR(Base):
                 for b in range(B):
                     hist[k][b, maxp - n_prefix[b]: maxp + 1] = first_logits[k][foff[b]:foff[b + 1]]
             row_start = self._i32([b * hcap + maxp - int(n_prefix[b]) for b in range(B)])
+            row_count0 = self._i32([int(n) + 1 for n in n_prefix])             # rows at step 0; step n reads n more
             last = torch.empty((B, ld), dtype=torch.float32, device=dev)
-            for step in range(n_steps):
-                if step > 0:
-                    for k in range(2):
-                        # the step's logits land in their history row: logits_out = hist[k][:, maxp + step], row stride hcap * ld
-                        states[k][0].max_ctx = states[k][2] + step - 1
-                        L.check(lib.valle_ar_decode(self._handle, C.byref(states[k][0]), None, 1,
-                                                    C.c_void_p(hist[k].data_ptr() + (maxp + step) * ld * 4), hcap * ld,
-                                                    L.ptr(ws), ws.numel(), stream))
-                # guidance over every response row so far (std over rows x vocab, samplers.py:187-188), last row out
-                row_count = self._i32([int(n) + step + 1 for n in n_prefix])
-                L.check(lib.valle_cfg_combine_last(L.ptr(hist[0]), L.ptr(hist[1]), ld, V, L.ptr(row_start), L.ptr(row_count), B,
-                                                   float(cfg_strength), float(cfg_rescale), L.ptr(last), ld, stream))
-                if return_logits:
-                    all_logits.append(last[:, :V].clone())
-                self._ar_sample_append(last, V, seq, seq_len, [states[0][1][2], states[1][1][2]], stopped, scores, sp, cap,
-                                       step=step, bump_ctx=step > 0)
-                if bool(stopped.all().item()):
+            # step 0: guidance over the prefill's response rows, last row out, sample + append (nothing to bump yet)
+            L.check(lib.valle_cfg_combine_last(L.ptr(hist[0]), L.ptr(hist[1]), ld, V, L.ptr(row_start), L.ptr(row_count0), B,
+                                               float(cfg_strength), float(cfg_rescale), L.ptr(last), ld, stream))
+            if return_logits:
+                all_logits.append(last[:, :V].clone())
+            self._ar_sample_append(last, V, seq, seq_len, [], stopped, scores, sp, cap, step=0)
+            # the other steps run on the device in chunks (valle_ar_decode_cfg: both caches, the combine over the histories,
+            # sampler + append), `stopped` is read once per chunk -- the reference syncs every step (ar_nar.py:846)
+            done = 1
+            while done < n_steps:
+                if bool(stopped.cpu().numpy().all()):
                     break
+                n = min(step_chunk, n_steps - done)
+                lasts = torch.empty((n, B, ld), dtype=torch.float32, device=dev) if return_logits else last
+                sp.offset = done
+                for k in range(2):
+                    states[k][0].max_ctx = states[k][2] + done - 1
+                L.check(lib.valle_ar_decode_cfg(self._handle, C.byref(states[0][0]), C.byref(states[1][0]), C.byref(sp), n, done,
+                                                L.ptr(hist[0]), L.ptr(hist[1]), ld, hcap, maxp, L.ptr(row_start), L.ptr(row_count0),
+                                                float(cfg_strength), float(cfg_rescale), L.ptr(lasts),
+                                                B * ld if return_logits else 0, L.ptr(ws), ws.numel(), stream))
+                if return_logits:
+                    all_logits.extend(lasts[j, :, :V] for j in range(n))
+                done += n
         return self._ar_finish(seq, seq_len, prefix, prefix_lens, prefix_context, start_slice, refine_on_stop, n_steps,
                                phns_list, lang_list, proms_list, return_logits, all_logits)
 
@@ -428,7 +435,7 @@ class AR_NAR(Base):
             if trace is not None:
                 trace.append(metrics)
             self._ar_sample_append(forced, V, seq, seq_len, [ctx_len], stopped, scores, greedy, cap, step=step, bump_ctx=step > 0)
-            if bool(stopped.all().item()):
+            if bool(stopped.cpu().numpy().all()):
                 break
         return self._ar_finish(seq, seq_len, prefix, prefix_lens, prefix_context, start_slice, False, n_steps,
                                phns_list, lang_list, proms_list, False, [])
@@ -482,7 +489,7 @@ class AR_NAR(Base):
             if return_logits:
                 all_logits.append(logits[:, :V].clone())
             self._ar_sample_append(logits, V, seq, seq_len, [], stopped, scores, sp, cap, step=step)
-            if bool(stopped.all().item()):
+            if bool(stopped.cpu().numpy().all()):
                 break
         return all_logits
 
