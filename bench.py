@@ -41,6 +41,17 @@ MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 FRAME_RATE = 75.0
 
 
+def newest_profile(suffix):
+    """profiles/r<N>_<suffix> of the highest round N (the PMC passes are committed per round), or None."""
+    import re
+    best = None
+    for f in (ROOT / "profiles").glob(f"r*_{suffix}"):
+        m = re.match(r"r(\d+)_", f.name)
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return None if best is None else best[1]
+
+
 def decode_step_bytes(cfg, B, ctx):
     """Algorithmic HBM bytes of one AR decode step, bf16, KV cache."""
     d, L, ff = cfg.dim, cfg.layers, cfg.dim * cfg.ffn
@@ -223,11 +234,15 @@ def main():
                 n1.record()
                 nar_prof.append((n0, n1))
             outs.extend(full)
-        out = torch.stack([f.to(torch.int16) for f in outs])            # (B, R, 8)
+        # the codes leave the device in one copy (int64 views of one buffer per call) and become the int16 block the job
+        # hands on; with several ranks that block goes back up for the gather (no conversion kernel of torch's on the way)
+        from vall_e_amd.models.ar_nar import _host_codes
+        host = np.stack(_host_codes(outs)).astype(np.int16)               # (B, R, 8)
+        out = torch.from_numpy(host)
         if dist is not None:
             raw = out.view(torch.uint8)                                 # RCCL has no int16: ship the bytes
-            if backend == "gloo":                                       # the CPU rehearsal backend gathers host tensors
-                raw = raw.cpu()
+            if backend != "gloo":                                       # (the CPU rehearsal backend gathers host tensors)
+                raw = raw.to(dev)
             if args.global_batch > 0 and B * world != total_utts:       # ragged shards: pad to the largest
                 pad = (total_utts + world - 1) // world - B
                 raw = torch.cat([raw, raw.new_zeros((pad,) + tuple(raw.shape[1:]))]) if pad else raw
@@ -236,7 +251,7 @@ def main():
             assert all(g.shape == raw.shape for g in gathered)
             step.gathered = [g.cpu().view(torch.int16) for g in gathered]
         else:
-            step.gathered = [out.cpu()]
+            step.gathered = [out]
         return out
 
     def fence():
@@ -274,8 +289,8 @@ def main():
             dec_bytes += decode_step_bytes(cfg, len(ctx0), [c + j for c in ctx0])
     roofline = None
     traffic, traffic_src = None, None
-    pmc = ROOT / "profiles" / "r2_pmc_decode_layer.json"
-    if dec_steps and pmc.exists():
+    pmc = newest_profile("pmc_decode_layer.json")
+    if dec_steps and pmc is not None:
         # HBM bytes per decode step from the PMC passes committed under profiles/ (FETCH_SIZE x2 on gfx950 +
         # WRITE_SIZE, collected on the same kernels at the bench's mean context): measured / algorithmic of one
         # layer, applied to this run's algorithmic bytes per step
@@ -298,10 +313,8 @@ def main():
         dense = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "what": f"7 NAR levels, {B} x {lens[0]} tokens each, host time included",
                  "ms": round(nar_ms, 2)}
-        mf = ROOT / "profiles" / "r2_pmc_mfma_dense_gemms.json"
-        if not mf.exists():
-            mf = ROOT / "profiles" / "r1_pmc_mfma_dense_gemms.json"
-        if mf.exists():     # MFMA pipe utilisation of the four layer GEMMs from the PMC pass committed under profiles/
+        mf = newest_profile("pmc_mfma_dense_gemms.json")
+        if mf is not None:  # MFMA pipe utilisation of the four layer GEMMs from the PMC pass committed under profiles/
             dense["mfma_busy_frac_pmc"] = {k.split("(")[0].replace("void ", ""): round(v["mfma_busy_frac"], 3)
                                            for k, v in json.loads(mf.read_text()).items()}
             dense["mfma_busy_source"] = f"profiles/{mf.name} (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 256 CUs x 4 SIMDs), tools/micro_gemm)"

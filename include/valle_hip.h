@@ -239,6 +239,11 @@ int valle_narlen_commit(int32_t* codes, float* scores, const uint8_t* is_masked,
 int valle_mask_lowest(const float* scores, int32_t* codes, uint8_t* is_masked, const int32_t* off,
                       const int32_t* k, int B, int max_len, int mask_token, void* stream);
 
+/* dst[0 .. n_words) = value (32-bit words), ordered on `stream` (hipMemsetD32Async, no compute kernel).  No counterpart in the
+ * reference (its torch.zeros / torch.full / torch.ones calls, e.g. models/ar_nar.py:337-339, :696): the host mirror
+ * initialises its device tables with it so that the tensor carrier launches no kernel of its own on the path. */
+int valle_fill32(void* dst, uint32_t value, size_t n_words, void* stream);
+
 /* ------------------------------------------------------------------- model level ---- */
 
 typedef struct {

@@ -35,7 +35,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&rope, 1024 * 64 * 4)); CK(hipMemset(rope, 0, 1024 * 64 * 4));
     CK(hipMalloc(&pos, (size_t)M * 4)); CK(hipMemset(pos, 0, (size_t)M * 4));
     const bool unfused = getenv("MICRO_GEMM_UNFUSED") != nullptr;
+    const char* only = getenv("MICRO_GEMM_ONLY");          // "qkv" | "o" | "gu" | "down": that GEMM alone (PMC passes per shape)
     for (auto& sh : shapes) {
+        if (only && (sh.epi < 0 || strncmp(sh.name, only, strlen(only)) != 0 || sh.name[strlen(only)] != ' ')) continue;
         const int ldc = (sh.epi == VALLE_EPI_GEGLU || sh.epi == -2) ? sh.N / 2 : sh.N;
         auto run = [&]() -> int {
             if (sh.epi == -1) return valle_gemm(A, W, nullptr, nullptr, C, M, sh.N, sh.K, ldc, VALLE_EPI_STORE, VALLE_BF16, s);

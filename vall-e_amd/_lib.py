@@ -86,6 +86,7 @@ SIGNATURES = {
     "valle_scatter_cols": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "valle_narlen_commit": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "valle_mask_lowest": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "valle_fill32": (c_int, [c_void_p, C.c_uint32, c_size_t, c_void_p]),
     "valle_model_create": (c_int, [C.POINTER(Config), c_void_p, c_void_p, C.POINTER(LayerWeights), c_void_p, c_int,
                                    C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(C.c_int32), C.POINTER(c_void_p), C.POINTER(c_void_p)]),
     "valle_model_destroy": (None, [c_void_p]),

@@ -85,6 +85,16 @@ extern "C" void valle_model_destroy(valle_model* m) {
     free(m->layers); free((void*)m->head_w); free((void*)m->head_b); free(m->head_n); free((void*)m->head_pn); free(m);
 }
 
+// ------------------------------------------------------------------ buffer initialisation without a compute kernel
+// 32-bit fill on the stream (hipMemsetD32Async): the host mirror initialises its device tables with it, so that the
+// allocator carrier (torch) launches no fill / arange kernel of its own on the product path.
+extern "C" int valle_fill32(void* dst, uint32_t value, size_t n_words, void* stream) {
+    VALLE_REQUIRE(dst || n_words == 0, VALLE_E_ARG, "valle_fill32: null pointer");
+    if (n_words == 0) return VALLE_OK;
+    VALLE_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)dst, (int)value, n_words, (hipStream_t)stream));
+    return VALLE_OK;
+}
+
 // ------------------------------------------------------------------ small helpers
 template <typename T>
 __global__ __launch_bounds__(128) void gather_rows_kernel(const T* __restrict__ x, const int32_t* __restrict__ rows,

@@ -34,8 +34,18 @@ def _host_codes(tensors):
     """list of (R_i, L) integer tensors -> list of int64 numpy arrays, with ONE device->host copy when
     they live on a GPU (a .cpu() per utterance costs ~40 us of synchronisation each)."""
     if all(isinstance(t, torch.Tensor) and t.is_cuda for t in tensors) and len({t.shape[1:] for t in tensors}) == 1:
-        flat = torch.cat(list(tensors)).cpu().numpy().astype(np.int64) if len({t.dtype for t in tensors}) == 1 else \
-            torch.cat([t.long() for t in tensors]).cpu().numpy()
+        t0 = tensors[0]
+        chained = len({t.dtype for t in tensors}) == 1 and all(
+            t.is_contiguous() and t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() for t in tensors) and all(
+            b.storage_offset() == a.storage_offset() + a.numel() for a, b in zip(tensors, tensors[1:]))
+        if chained:
+            # consecutive views of one buffer (what forward_ar / forward_nar return): one copy of that range, no cat kernel
+            rows = sum(t.shape[0] for t in tensors)
+            whole = t0.new_empty(0).set_(t0.untyped_storage(), t0.storage_offset(), (rows,) + tuple(t0.shape[1:]))
+            flat = whole.cpu().numpy().astype(np.int64)
+        else:
+            flat = torch.cat(list(tensors)).cpu().numpy().astype(np.int64) if len({t.dtype for t in tensors}) == 1 else \
+                torch.cat([t.long() for t in tensors]).cpu().numpy()
         cuts = np.cumsum([0] + [t.shape[0] for t in tensors])
         return [flat[cuts[i]:cuts[i + 1]] for i in range(len(tensors))]
     return [_np(t) for t in tensors]
@@ -230,14 +240,14 @@ class AR_NAR(Base):
         ld = _round_up(V, 8)
         H, Dh, Lyr = self.n_heads, self.d_model // self.n_heads, self.n_layers
         cap = max(len(p) for p in prefix) + n_steps + 1
-        seq = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+        seq = self._filled((B, cap), torch.int32)
         for i, p in enumerate(prefix):
             if len(p):
                 seq[i, : len(p)] = torch.from_numpy(p.astype(np.int32)).to(dev)
         seq_len = self._i32([len(p) for p in prefix])
-        stopped = torch.zeros(B, dtype=torch.int32, device=dev)
-        scores = torch.zeros(B, dtype=torch.float32, device=dev)
-        slot = torch.arange(B, dtype=torch.int32, device=dev)
+        stopped = self._filled(B, torch.int32)
+        scores = self._filled(B, torch.float32)
+        slot = self._i32(np.arange(B))
 
         # A [task, codes] prompt makes the reference's position ids one short per task token (base.py:964-990): every row
         # behind the prompt reads its neighbour's id and the LAST row -- the newest token -- always gets 1, so a token's
@@ -266,7 +276,7 @@ class AR_NAR(Base):
             # guidance needs the logits of every response row so far (samplers.py:178-189): with a prefix those are
             # the prefill's last len(prefix) + 1 rows
             rows, off = self.tail_rows(plan, [len(p) + 1 for p in prefix] if cfg_strength > 0 else [1] * B)
-            pos0 = torch.zeros(B, dtype=torch.int32, device=dev)
+            pos0 = self._filled(B, torch.int32)
             lg = self.forward_dense(plan, rows, cache=(kc, vc, cache_T, stride, slot, pos0))
             ctx_len = self._i32(plan.lens)
             # RoPE position of response token 0: per-segment position ids restart at 0 (base.py:984); with
@@ -343,7 +353,7 @@ class AR_NAR(Base):
             n_prefix = np.array([len(p) for p in prefix], dtype=np.int64)
             maxp = int(n_prefix.max())
             hcap = maxp + n_steps + 1
-            hist = [torch.zeros((B, hcap, ld), dtype=torch.float32, device=dev) for _ in range(2)]
+            hist = [self._filled((B, hcap, ld), torch.float32) for _ in range(2)]
             foff = np.concatenate(([0], np.cumsum(n_prefix + 1)))
             for k in range(2):                                                 # the prefill's rows open the histories
                 for b in range(B):
@@ -393,7 +403,7 @@ class AR_NAR(Base):
         V = self.cls_tokens[0]
         ld = _round_up(V, 8)
         H, Dh, Lyr = self.n_heads, self.d_model // self.n_heads, self.n_layers
-        slot = torch.arange(B, dtype=torch.int32, device=dev)
+        slot = self._i32(np.arange(B))
         plan = self.plan(phns_list, lang_list, proms_list, [torch.from_numpy(p) for p in prefix], 0)
         if plan.max_T + n_steps + 1 > self.max_position_embeddings:
             raise ValueError(f"sequence of {plan.max_T} + {n_steps} steps exceeds max_position_embeddings ({self.max_position_embeddings})")
@@ -403,7 +413,7 @@ class AR_NAR(Base):
         vc = torch.empty_like(kc)
         rows, off = self.tail_rows(plan, plan.lens)                          # every row: the ranking sums over all of them
         last_rows = (plan.cu[1:] - 1).astype(np.int32)
-        pos0 = torch.zeros(B, dtype=torch.int32, device=dev)
+        pos0 = self._filled(B, torch.int32)
         lg, sc = self.forward_dense(plan, rows, cache=(kc, vc, cache_T, stride, slot, pos0), score_rows=last_rows)
         ctx_len = self._i32(plan.lens)
         resp_pos0 = self._i32([plan.lens[i] - len(prefix[i]) if self.unified_position_ids else 0 for i in range(B)])
@@ -419,7 +429,7 @@ class AR_NAR(Base):
         greedy = self.sample_params(temperature=0.0, top_no=0.0)
         kws = dict(temperature=kw.get("temperature", 1.0), top_k=kw.get("top_k", -100), top_p=kw.get("top_p", 1.0), seed=kw.get("seed", 0))
         step_lg = torch.empty((B, ld), dtype=torch.float32, device=dev)
-        step_sc = torch.zeros((B, H, cache_T), dtype=torch.float32, device=dev)
+        step_sc = self._filled((B, H, cache_T), torch.float32)
         for step in range(n_steps):
             if step == 0:
                 cur, cur_rows, cur_sc = lg, last_rows, sc
@@ -600,7 +610,7 @@ class AR_NAR(Base):
         bases = [self._off[f"resp{l + 1}"] for l in range(n_lv - 1)]
         # integer tables patched by valle_scatter_cols: resp_idx = embedding rows of the codes so far, flat = the codes
         # themselves (int64, what the call returns), prev_col = the newest level (the sampler's `prev`)
-        resp_idx = torch.full((total, 8), -1, dtype=torch.int32, device=self.device)
+        resp_idx = self._filled((total, 8), torch.int32, -1)
         flat = torch.empty((total, levels[-1] + 1), dtype=torch.int64, device=self.device)
         prev_col = torch.empty(total, dtype=torch.int32, device=self.device)
         for l in range(level0):
@@ -667,8 +677,8 @@ class AR_NAR(Base):
         off = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
         off_d = self._i32(off)
         total = int(off[-1])
-        codes = torch.full((total,), self.mask_token, dtype=torch.int32, device=dev)
-        scores = torch.ones(total, dtype=torch.float32, device=dev)
+        codes = self._filled((total,), torch.int32, self.mask_token)
+        scores = self._filled(total, torch.float32, 1.0)
         is_masked = torch.empty(total, dtype=torch.uint8, device=dev)
         prev_codes = torch.empty(total, dtype=torch.int32, device=dev)
         null_text = self._null_text(phns_list)

@@ -502,6 +502,16 @@ class Base:
             ws = self._ws[key] = torch.empty(_round_up(nbytes, 1 << 20), dtype=torch.uint8, device=self.device)
         return ws
 
+    def _filled(self, shape, dtype, value=0):
+        """A device tensor of a 4-byte dtype with every element = value, initialised by valle_fill32 on the current stream
+        (torch.zeros / full / ones would launch a fill kernel of torch's own)."""
+        assert dtype in (torch.int32, torch.float32)
+        t = torch.empty(shape, dtype=dtype, device=self.device)
+        if t.numel():
+            word = int(np.array(value, dtype=np.float32 if dtype == torch.float32 else np.int32).view(np.uint32))
+            L.check(L.load().valle_fill32(L.ptr(t), word, t.numel(), L.stream_ptr(self.device)))
+        return t
+
     def _i32(self, arr):
         return self._h2d(np.ascontiguousarray(arr, dtype=np.int32))
 
@@ -559,7 +569,7 @@ class Base:
             # output_attentions: also the last layer's raw attention products of the packed rows in score_rows, over every
             # key of their utterance -> (n_score, H, max_T) fp32 (valle_forward_dense_scores)
             srows = self._i32(score_rows)
-            scores = torch.zeros((len(score_rows), self.n_heads, plan.max_T), dtype=torch.float32, device=self.device)
+            scores = self._filled((len(score_rows), self.n_heads, plan.max_T), torch.float32)
             L.check(lib.valle_forward_dense_scores(self._handle, L.ptr(idx), L.ptr(pos), L.ptr(cu), plan.B, plan.M, plan.max_T, causal,
                                                    L.ptr(kc), L.ptr(vc), cache_T, stride, L.ptr(slot), L.ptr(pos0),
                                                    L.ptr(rows), n_out, plan.head, L.ptr(logits), ld, L.ptr(hidden),
