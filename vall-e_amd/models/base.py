@@ -241,13 +241,13 @@ class Base:
             wq, wk, wv = (sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv")
             host = {"qkv": torch.cat((wq[perm], wk[perm], wv)).to(dt)}          # host copies in the storage dtype
             b[f"qkv{l}"] = host["qkv"].to(dev).contiguous()
-            b[f"o{l}"] = sd[p + "self_attn.o_proj.weight"].to(dev, dt).contiguous()
+            b[f"o{l}"] = sd[p + "self_attn.o_proj.weight"].to(dt).contiguous().to(dev)
             gu = torch.stack((sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]), dim=1).reshape(2 * ff, d)
             host["gu"] = gu.to(dt)
             b[f"gu{l}"] = host["gu"].to(dev).contiguous()
-            b[f"down{l}"] = sd[p + "mlp.down_proj.weight"].to(dev, dt).contiguous()
-            b[f"ln1_{l}"] = sd[p + "input_layernorm.weight"].to(dev, dt).contiguous()
-            b[f"ln2_{l}"] = sd[p + "post_attention_layernorm.weight"].to(dev, dt).contiguous()
+            b[f"down{l}"] = sd[p + "mlp.down_proj.weight"].to(dt).contiguous().to(dev)
+            b[f"ln1_{l}"] = sd[p + "input_layernorm.weight"].to(dt).contiguous().to(dev)
+            b[f"ln2_{l}"] = sd[p + "post_attention_layernorm.weight"].to(dt).contiguous().to(dev)
             packed = [None] * 6
             if dt == torch.bfloat16 and d % 64 == 0:
                 for j, n in enumerate(("o", "down")):
@@ -280,7 +280,7 @@ class Base:
         # concatenated embedding table (row offsets: _table_offsets)
         tabs = [sd[key].reshape(-1, d) for _, key in self._table_order]
         b = self._bufs
-        b["emb"] = torch.cat(tabs).to(dev, dt).contiguous()
+        b["emb"] = torch.cat(tabs).to(dt).contiguous().to(dev)
         # RoPE table, computed exactly as the reference does (arch/llama.py:118-127): fp32
         # outer product of positions and inv_freq, then cos / sin
         Dh = d // H
@@ -289,15 +289,15 @@ class Base:
         freqs = (inv_freq[None, :, None] @ pos[None, None, :]).transpose(1, 2)[0]      # (P, Dh/2)
         b["rope"] = torch.stack((freqs.cos(), freqs.sin()), dim=-1).to(dev).contiguous()  # (P, Dh/2, 2) fp32
         layers = self._build_layers(sd)
-        b["norm"] = sd["model.norm.weight"].to(dev, dt).contiguous()
+        b["norm"] = sd["model.norm.weight"].to(dt).contiguous().to(dev)
         n_cls = len(self.cls_tokens)
         hw, hb, hn, hpn = (C.c_void_p * n_cls)(), (C.c_void_p * n_cls)(), (C.c_int32 * n_cls)(), (C.c_void_p * n_cls)()
         for k in range(n_cls):
-            b[f"hw{k}"] = sd[f"classifiers.proj.{k}.weight"].to(dev, dt).contiguous()
+            b[f"hw{k}"] = sd[f"classifiers.proj.{k}.weight"].to(dt).contiguous().to(dev)
             hw[k] = b[f"hw{k}"].data_ptr()
             bias = sd.get(f"classifiers.proj.{k}.bias")
             if bias is not None:
-                b[f"hb{k}"] = bias.to(dev, torch.float32).contiguous() if dt == torch.float32 else bias.to(dt).to(dev, torch.float32).contiguous()
+                b[f"hb{k}"] = bias.to(dt).to(torch.float32).contiguous().to(dev)     # rounded to the storage dtype, held in fp32 (on the host: no device kernel)
                 hb[k] = b[f"hb{k}"].data_ptr()
             else:
                 hb[k] = None
