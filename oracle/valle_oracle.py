@@ -839,12 +839,24 @@ class Oracle:
         self.set_lora_level(0)                                           # ar_nar.py:262-269
         resps = [torch.full((n,), self.mask_token, dtype=torch.int64) for n in lens]
         scores = [torch.ones(n, dtype=torch.float32) for n in lens]
+        given = kw.pop("resps_list", None)
+        stable_ties = start > 0.0 and given is not None
+        if stable_ties:                                                  # ar_nar.py:328-334: denoise an existing sequence; the
+            import random                                                # 0 / 1 scores come from Python's global ``random``
+            resps = [(r if r.dim() == 1 else r[:, 0]).long()[:n] for r, n in zip(given, lens)]
+            noise_p0 = math.cos(start * math.pi * 0.5)
+            scores = [torch.tensor([0.0 if random.random() < noise_p0 else 1.0 for _ in range(n)], dtype=torch.float32) for n in lens]
         null_phn = [RawText([1, 2]) if isinstance(phns[i], RawText) else torch.tensor([1, 2]) for i in range(B)]
         for step, t in enumerate(torch.linspace(start, end, max_steps)):
             noise_p = math.cos(t * math.pi * 0.5)
             mask_p = noise_p + (1.0 / (max_steps * 2) if remask else 0)
             prev = resps
-            idx = [s.topk(clamp(int(mask_p * n), 1, n - step), dim=-1, largest=False).indices for s, n in zip(scores, lens)]
+            if stable_ties:
+                # (the reference's topk leaves the order among tied scores to the torch build; the 0 / 1 start scores of this
+                # mode are all ties, so this restatement -- like the HIP kernel -- breaks them by the lower index: NOT pinned)
+                idx = [torch.sort(s, stable=True).indices[: clamp(int(mask_p * n), 1, n - step)] for s, n in zip(scores, lens)]
+            else:
+                idx = [s.topk(clamp(int(mask_p * n), 1, n - step), dim=-1, largest=False).indices for s, n in zip(scores, lens)]
             resps = [r.scatter(0, i, self.mask_token) for r, i in zip(resps, idx)]
             is_masked = [r == self.mask_token for r in resps]
             temp = temperature * (1.0 - float(t)) if annealed else temperature

@@ -312,21 +312,23 @@ def test_derive_seed_separates_chunks_ranks_and_phases():
     assert derive_seed(None) != derive_seed(None)
 
 
-def test_from_dict_refuses_unbuilt_experimental_switches():
-    """A checkpoint's metadata that sets a switch the HIP path does not implement must not load silently."""
+def test_from_dict_accepts_the_switches_the_reference_ignores():
+    """Experimental switches that the reference's version-5 model never reads (see Model.from_dict for the file:line of each)
+    load and change nothing, as there; the two that do change its forward and are not built are refused by the model."""
     from vall_e_amd.config import Model
+    from vall_e_amd.models import get_model
     ok = Model.from_dict({"size": "full", "experimental": {"audio_embedding_sums": True, "rvq_levels_p": "equal", "layerskip_r": 2,
-                                                           "kv_heads": 0, "tie_classifier_to_embedding": False}})
+                                                           "kv_heads": 0, "tie_classifier_to_embedding": False, "split_classifiers": True}})
     assert ok.experimental.audio_embedding_sums is True
-    for bad in ({"tie_classifier_to_embedding": True}, {"interleave": True}, {"hf": True}, {"audio_embedding_mode": "inclusive"},
-                {"logit_normalization": 1.0}, {"use_sliding_attention_mask": True}):
+    for ignored in ({"tie_classifier_to_embedding": True}, {"interleave": True}, {"hf": True}, {"audio_embedding_mode": "inclusive"},
+                    {"logit_normalization": 1.0}, {"use_sliding_attention_mask": True}, {"kv_heads": 4}, {"predict_causally": True}):
+        cfg = Model.from_dict({"size": "full", "experimental": dict(ignored, split_classifiers=True, audio_embedding_sums=True)})
+        assert cfg.to_dict()["experimental"] == ok.to_dict()["experimental"]        # nothing of it reaches the model
+        get_model(cfg)
+    Model.from_dict({"size": {"dim": 1024, "heads": 16, "layers": 12, "embed_dim": 512}})
+    for refused in ({"split_classifiers": False}, {"split_classifiers": True, "causal_size": 2}):
         with pytest.raises(NotImplementedError):
-            Model.from_dict({"size": "full", "experimental": bad})
-    with pytest.raises(NotImplementedError):
-        Model.from_dict({"size": {"dim": 1024, "heads": 16, "layers": 12}, "experimental": {"kv_heads": 4}})
-    with pytest.raises(NotImplementedError):
-        Model.from_dict({"size": {"dim": 1024, "heads": 16, "layers": 12, "embed_dim": 512}})
-    Model.from_dict({"size": {"dim": 1024, "heads": 16, "layers": 12, "embed_dim": 1024}, "experimental": {"kv_heads": 16}})
+            get_model(Model.from_dict({"size": "full", "experimental": refused}))
 
 
 def test_hf_token_ranges_and_round_trip():

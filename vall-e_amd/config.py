@@ -101,21 +101,19 @@ class Model:
             exp_obj = exp
         else:
             known = {f.name for f in fields(ModelExperimentalSettings)}
-            # switches of the reference (config.py:268-354) that change what the forward computes and are not built here:
-            # a checkpoint that sets one must not load and silently run with other semantics.  Everything else that is
-            # dropped below only steers training (loss factors, dropout odds, level sampling).
-            probe = cls(size=d.get("size", "full"))
-            dim, heads = probe.dim, probe.heads
-            unbuilt = {"hf": False, "interleave": False, "audio_embedding_mode": None, "tie_classifier_to_embedding": False,
-                       "monolithic_audio_encoder": False, "logit_normalization": 0, "use_segmented_attention_mask": False,
-                       "use_sliding_attention_mask": False, "predict_causally": False}
-            for k, off in unbuilt.items():
-                if k in exp and exp[k] != off and exp[k]:
-                    raise NotImplementedError(f"experimental.{k}={exp[k]!r} is not built on the HIP path")
-            if exp.get("kv_heads", 0) not in (0, heads, None):
-                raise NotImplementedError(f"experimental.kv_heads={exp['kv_heads']}: grouped-query attention is not built (MHA only)")
-            if isinstance(d.get("size"), dict) and d["size"].get("embed_dim", dim) != dim:
-                raise NotImplementedError(f"size.embed_dim={d['size']['embed_dim']} != dim: separate embedding width is not built")
+            # Switches of the reference's dataclass (config.py:268-354) that this build does not model are ACCEPTED AND IGNORED,
+            # because the reference's version-5 model ignores them too -- a checkpoint that sets one runs with the same
+            # semantics there as here:
+            #   hf, interleave, logit_normalization, use_segmented_attention_mask, use_sliding_attention_mask: never read by
+            #     models/base.py / models/ar_nar.py / models/arch/llama.py (the attention-mask switches belong to base_v2.py);
+            #   tie_classifier_to_embedding, audio_embedding_mode, monolithic_audio_encoder: read into locals of
+            #     Base.__init__ (models/base.py:368-369, :381) and not used again;
+            #   predict_causally: training only (models/base.py:1033 calc_loss, models/ar_nar.py:182 forward_train);
+            #   kv_heads: models/base.py:478 hard-wires num_key_value_heads = n_heads; size.embed_dim: a property of the
+            #     dataclass only (config.py:472-476).
+            # The switches that DO change the version-5 forward are fields of ModelExperimentalSettings here and are either
+            # built (audio_embedding_sums, unified_position_ids, noncausal_masks, classifiers_bias, max_position_embeddings,
+            # masking_ratio) or refused by Base.__init__ (split_classifiers=False, causal_size != 1).
             exp_obj = ModelExperimentalSettings(**{k: v for k, v in exp.items() if k in known})
         known = {f.name for f in fields(cls)} - {"experimental"}
         return cls(experimental=exp_obj, **{k: v for k, v in d.items() if k in known})

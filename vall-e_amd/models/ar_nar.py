@@ -667,9 +667,10 @@ class AR_NAR(Base):
         masked_only = kw.pop("sampling_scores_masked_only", False)
         trace = kw.pop("trace", None)          # list: receives (ids, scores) of every demasking step, packed rows (tests)
         if kw.get("vc_list") is not None:
-            raise NotImplementedError("vc_list is not built on the HIP path")
-        if start_noise > 0.0:
-            raise NotImplementedError("denoising from an existing sequence (denoise_start > 0)")
+            # ar_nar.py:366-377 writes ``resp.scatter(0, indices, half_mask)``: source element i lands at the i-th index of
+            # topk's output, and at the first step every score is 1.0, so WHICH source code lands where is decided by the
+            # order torch.topk returns tied entries in -- an internal of the torch build and device, not of the algorithm
+            raise NotImplementedError("vc_list is not built on the HIP path (its result depends on torch.topk's order among tied scores)")
         if quant_levels is not None and any(q != 0 for q in quant_levels):
             raise NotImplementedError("demasking levels other than 0")
         lens = [clamp(int(l), min_length, max_length) for l in len_list]
@@ -677,8 +678,24 @@ class AR_NAR(Base):
         off = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
         off_d = self._i32(off)
         total = int(off[-1])
-        codes = self._filled((total,), torch.int32, self.mask_token)
-        scores = self._filled(total, torch.float32, 1.0)
+        if start_noise > 0.0 and resps_list is not None:
+            # denoising from an existing sequence (ar_nar.py:328-334): the given level-0 codes stay, and every position draws a
+            # score of 0 with probability cos(start * pi / 2), else 1 -- from Python's global ``random``, as the reference does
+            # (seed it the same way and the scores are the same).  The first step then masks the k lowest of these tied scores:
+            # among ties valle_mask_lowest takes the lower index, torch.topk whatever its build does -- the masked SET may
+            # differ from the reference's there, its size and the "lowest scores first" rule do not.
+            import random
+            given = _host_codes([r if r.dim() == 1 else r[:, :1] for r in resps_list])
+            given = [g.reshape(-1)[:n] for g, n in zip(given, lens)]
+            if any(len(g) != n for g, n in zip(given, lens)):
+                raise ValueError("denoise_start: resps_list must hold len_list[i] frames per utterance")
+            noise_p0 = math.cos(start_noise * math.pi * 0.5)
+            sc_h = [[0.0 if random.random() < noise_p0 else 1.0 for _ in range(n)] for n in lens]
+            codes = self._i32(np.concatenate(given))
+            scores = self._h2d(np.concatenate([np.asarray(x, dtype=np.float32) for x in sc_h]))
+        else:
+            codes = self._filled((total,), torch.int32, self.mask_token)
+            scores = self._filled(total, torch.float32, 1.0)
         is_masked = torch.empty(total, dtype=torch.uint8, device=dev)
         prev_codes = torch.empty(total, dtype=torch.int32, device=dev)
         null_text = self._null_text(phns_list)
