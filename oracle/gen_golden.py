@@ -103,8 +103,21 @@ def get_ref_model(kind, dtype=torch.float32, **synth_kw):
     lora = synth_kw.pop("lora", None)              # (rank, alpha, rvq_levels): the reference's LoRA path, engines/__init__.py:102-103
     mcfg = {"full": vcfg.repo_default_model, "tiny": vcfg.tiny_model, "tiny_len": vcfg.tiny_len_model,
             "tiny_nc": vcfg.tiny_nc_model, "tiny_tone": vcfg.tiny_tone_model, "tiny_upi": vcfg.tiny_upi_model, "tiny_nobias": vcfg.tiny_nobias_model, "tiny_nc_upi": vcfg.tiny_nc_upi_model, "tiny_nosum": vcfg.tiny_nosum_model, "tiny_sumprom": vcfg.tiny_sumprom_model,
-            "half2": lambda: vcfg.tiny_model(dim=512, heads=8), "s075_2": lambda: vcfg.tiny_model(dim=768, heads=12)}[kind]()
-    model = rh.build_reference_model(size=mcfg.size, capabilities=list(mcfg.capabilities),
+            "half2": lambda: vcfg.tiny_model(dim=512, heads=8), "s075_2": lambda: vcfg.tiny_model(dim=768, heads=12),
+            "tiny_v2": vcfg.tiny_v2_model, "tiny_v2_nc": vcfg.tiny_v2_nc_model}[kind]()
+    if mcfg.version >= 7:
+        model = rh.build_reference_model(size=mcfg.size, capabilities=list(mcfg.capabilities), version=mcfg.version,
+                                         noncausal_masks=mcfg.experimental.noncausal_masks,
+                                         unified_position_ids=mcfg.experimental.unified_position_ids)
+        assert type(model).__name__ == "AR_NAR_V2"
+        sd = synth_state_dict(mcfg, synth_kw.pop("weight_seed", WEIGHT_SEED), **synth_kw)
+        model.load_state_dict(sd, strict=True)
+        ref_cfg.loras = []
+        model = model.to(dtype).eval()
+        _models.clear()
+        _models[key] = (model, mcfg, [])
+        return model, mcfg
+    model = rh.build_reference_model(version=mcfg.version, size=mcfg.size, capabilities=list(mcfg.capabilities),
                                      noncausal_masks=mcfg.experimental.noncausal_masks,
                                      unified_position_ids=mcfg.experimental.unified_position_ids,
                                      classifiers_bias=mcfg.experimental.classifiers_bias,
@@ -991,6 +1004,72 @@ def scen_entropix():
     save("tiny_entropix", **out)
 
 
+def scen_tiny_v2():
+    """The version-7 model (reference models/base_v2.py, models/ar_nar_v2.py: all eight codebooks per frame, AudioEncoder /
+    AudioDecoder around the same llama stack) on the tiny configuration:
+    tiny_v2_fwd      embeddings, position ids and logits of one AR-style pass (resps (R, 8)) and one demasking-style pass
+                     (time_list given, some codes = mask token)
+    tiny_v2_ar       greedy AR, 6 steps of 8 codes, the smallest top-2 margin over every (step, level)
+    tiny_v2_narlen   NAR-len demasking of all levels (4 steps, guidance floor 2.5 / rescale 0.75), causal and noncausal_masks"""
+    ref = rh.load_reference()
+    model, mcfg = get_ref_model("tiny_v2")
+    g = torch.Generator().manual_seed(808)
+    phns, proms, langs = synth_batch(41, 2, n_phn=10, n_prom=15, ragged=True)
+    resps = [torch.randint(0, 1024, (n, 8), generator=g).to(torch.int16) for n in (7, 11)]
+    d = input_arrays(phns, proms, langs)
+    with torch.inference_mode():
+        inputs = model.inputs(task_list=["tts"] * 2, phns_list=phns, proms_list=proms, resps_list=resps, lang_list=langs, quant_levels=[0, 0])
+        x_list = model.inputs_to_embeddings(inputs, [0, 0])
+        out = model.forward_super(inputs=inputs, quant_levels=[0, 0])
+        for i in range(2):
+            d[f"ar_resp_{i}"], d[f"ar_emb_{i}"], d[f"ar_logits_{i}"] = resps[i], x_list[i], out.logits[i][:, -3:]      # logits (8, T, 1025): last rows
+        from vall_e.models.base_v2 import list_to_tensor
+        _, mask = list_to_tensor(x_list)
+        d["ar_pos"] = model.inputs_to_position_ids(inputs, mask=mask)
+        masked = [r.clone() for r in resps]
+        for r in masked:
+            r[torch.rand(r.shape, generator=g) < 0.5] = model.mask_token
+        t = torch.tensor(0.3)
+        inputs = model.inputs(task_list=["tts"] * 2, phns_list=phns, proms_list=proms, resps_list=masked, lang_list=langs,
+                              time_list=[t, t], quant_levels=[0, 0])
+        out = model.forward_super(inputs=inputs, quant_levels=[0, 0])
+        for i in range(2):
+            d[f"nar_resp_{i}"], d[f"nar_logits_{i}"] = masked[i], out.logits[i][:, -masked[i].shape[0]:][:, ::3]    # every third response row
+    save("tiny_v2_fwd", **d)
+
+    import vall_e.models.base_v2 as rb2
+    for name, kw in (("tiny_v2_ar", {}),):
+        gaps = []
+        orig = rb2.Base_V2.sample
+        def wrapped(self_, logits, *a, **k):
+            for l in logits:
+                v = torch.topk(l[..., -1, :].float(), 2).values
+                gaps.append(float((v[..., 0] - v[..., 1]).min()))
+            return orig(self_, logits, *a, **k)
+        rb2.Base_V2.sample = wrapped
+        try:
+            codes = run_ar(model, phns, proms, langs, max_duration=6, temperature=0.0, **kw)
+        finally:
+            rb2.Base_V2.sample = orig
+        o = input_arrays(phns, proms, langs)
+        o.update(pack_list("ar_codes", codes))
+        o["steps"], o["min_top2_gap"] = np.int64(6), np.float64(min(gaps))
+        for k_, v_ in kw.items():
+            o[f"kw_{k_}"] = np.float64(v_)
+        print(f"  [{name}] codes {codes[0].tolist()[:2]} min top-2 gap {min(gaps):.3e}")
+        save(name, **o)
+
+    for name, kind in (("tiny_v2_narlen", "tiny_v2"), ("tiny_v2_nc_narlen", "tiny_v2_nc")):
+        model, mcfg = get_ref_model(kind)
+        lens = [9, 12]
+        codes = run_narlen(model, phns, proms, langs, lens, max_steps=4, temperature=0.0)
+        o = input_arrays(phns, proms, langs)
+        o.update(pack_list("codes", codes))
+        o["lens"], o["max_steps"] = np.array(lens), np.int64(4)
+        print(f"  [{name}] {[tuple(c.shape) for c in codes]} {codes[0][:2].tolist()}")
+        save(name, **o)
+
+
 def scen_full_b3():
     mk = lambda s: synth_batch(s, 3, n_phn=30, n_prom=60, ragged=True)
     ar_nar_scenario("full_b3", "full", mk, 61, steps=12)
@@ -1046,6 +1125,7 @@ SCENARIOS = {
     "tiny_beam": scen_tiny_beam,
     "mirostat_kat": scen_mirostat_kat,
     "entropix": scen_entropix,
+    "tiny_v2": scen_tiny_v2,
     "full_b1": scen_full_b1,
     "long": scen_long,
     "full_b3": scen_full_b3,

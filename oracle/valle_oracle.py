@@ -564,7 +564,7 @@ class Oracle:
         rot = torch.cat((-x[..., h:], x[..., :h]), dim=-1)
         return x * cos + rot * sin
 
-    def stack(self, x, pos, lens, kv=None, layer_probe=None, causal=None, score_probe=None):
+    def stack(self, x, pos, lens, kv=None, layer_probe=None, causal=None, score_probe=None, final_norm=True):
         """x: packed (sum(lens), d); pos: packed position ids; lens: rows per utterance.
         kv: optional list (per layer) of per-utterance [K, V] caches that are appended to
         (KV-cache mode); attention then runs each new row against cache + new rows.
@@ -613,7 +613,8 @@ class Oracle:
             x = x + self._lin(g * u, p + "mlp.down_proj")
             if layer_probe is not None and l == 0:
                 layer_probe["layer0"] = x
-        x = self.rms_norm(x, self.w["model.norm.weight"])
+        if final_norm:                                               # (the version >= 7 model moves it into its decoder)
+            x = self.rms_norm(x, self.w["model.norm.weight"])
         if layer_probe is not None:
             layer_probe["final"] = x
         return x

@@ -69,3 +69,19 @@ def tiny_nc_upi_model(**kw) -> Model:
     m = tiny_nc_model(**kw)
     m.experimental.unified_position_ids = True
     return m
+
+
+def tiny_v2_model(dim=256, heads=4, layers=2) -> Model:
+    """Tiny sibling of a version-7 model (reference models/base_v2.py, models/ar_nar_v2.py: all eight codebooks at once)
+    under the switches of data/config.yaml (per-segment position ids, causal masks) and the dataclass defaults of the
+    version >= 7 experimental fields."""
+    m = tiny_model(dim, heads, layers)
+    m.version = 7
+    return m
+
+
+def tiny_v2_nc_model(**kw) -> Model:
+    """``tiny_v2_model`` with ``noncausal_masks``: the demasking passes attend in both directions (base_v2.py:1182-1185)."""
+    m = tiny_v2_model(**kw)
+    m.experimental.noncausal_masks = True
+    return m

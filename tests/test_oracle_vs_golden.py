@@ -525,3 +525,45 @@ def test_tiny_entropix_ar():
     out = o.ar(phns, proms, langs, max_duration=steps, temperature=0.8, top_k=27, top_p=0.9, entropix_sampling=True)
     for b in range(2):
         np.testing.assert_array_equal(out[b].numpy(), z[f"ar_codes_k27_{b}"])
+
+
+# ------------------------------------------------------------------------------ version >= 7 model ("v2")
+def make_oracle_v2(kind):
+    import valle_oracle_v2 as vo2
+    return vo2.OracleV2(model_cfg(kind), synth_weights(kind))
+
+
+def test_tiny_v2_forward():
+    """The version-7 model's pass (reference models/base_v2.py): AudioEncoder embeddings and per-segment position ids equal
+    the reference's, the (8, T, 1025) logits of an AR-style pass and of a demasking-style pass (mask tokens in the codes)
+    within 1e-4."""
+    z = load_golden("tiny_v2_fwd")
+    phns, proms, langs = golden_inputs(z)
+    o = make_oracle_v2("tiny_v2")
+    resps = [torch.from_numpy(z[f"ar_resp_{i}"]) for i in range(2)]
+    logits, xs, ps = o.forward_v2(phns, langs, proms, resps, return_embeddings=True)
+    for i in range(2):
+        torch.testing.assert_close(xs[i], torch.from_numpy(z[f"ar_emb_{i}"]), rtol=1e-5, atol=1e-5)
+        np.testing.assert_array_equal(ps[i].numpy(), z["ar_pos"][i][: ps[i].shape[0]])
+        torch.testing.assert_close(logits[i][:, -3:], torch.from_numpy(z[f"ar_logits_{i}"]), rtol=1e-4, atol=1e-4)
+    masked = [torch.from_numpy(z[f"nar_resp_{i}"]) for i in range(2)]
+    logits = o.forward_v2(phns, langs, proms, masked, timestep=True)
+    for i in range(2):
+        n = masked[i].shape[0]
+        torch.testing.assert_close(logits[i][:, -n:][:, ::3], torch.from_numpy(z[f"nar_logits_{i}"]), rtol=1e-4, atol=1e-4)
+
+
+def test_tiny_v2_ar_and_narlen():
+    """Greedy AR of 8 codes per step (models/ar_nar_v2.py:433-589) and NAR-len demasking of all levels with the guidance on
+    (levels, rows, vocab) logits (:207-372, samplers.py:177-191), causal and with noncausal_masks: codes == the reference's."""
+    z = load_golden("tiny_v2_ar")
+    phns, proms, langs = golden_inputs(z)
+    out = make_oracle_v2("tiny_v2").ar_v2(phns, proms, langs, max_duration=int(z["steps"]), temperature=0.0)
+    for b in range(2):
+        np.testing.assert_array_equal(out[b].numpy(), z[f"ar_codes_{b}"])
+    for name, kind in (("tiny_v2_narlen", "tiny_v2"), ("tiny_v2_nc_narlen", "tiny_v2_nc")):
+        z = load_golden(name)
+        phns, proms, langs = golden_inputs(z)
+        out = make_oracle_v2(kind).nar_masked_v2(phns, proms, langs, [int(x) for x in z["lens"]], max_steps=int(z["max_steps"]), temperature=0.0)
+        for b in range(2):
+            np.testing.assert_array_equal(out[b].numpy(), z[f"codes_{b}"])

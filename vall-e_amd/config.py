@@ -23,6 +23,17 @@ class ModelExperimentalSettings:
     noncausal_masks: bool = False
     classifiers_bias: bool = True
     max_position_embeddings: int = 70 * 65 * 5
+    # read by the version >= 7 model only (vall_e/config.py:302-332, models/base_v2.py:293-316)
+    monolithic_audio_encoder: bool = False
+    per_level_normalization: bool = True
+    len_use_logits: bool = False
+    use_segmented_attention_mask: bool = False
+    use_sliding_attention_mask: bool = False
+    use_audio_encoder_level_weights: bool = True
+    use_audio_encoder_ffn: bool = True
+    use_audio_encoder_norm: bool = True
+    audio_decoder_ffn_expansion_size: int = 2
+    audio_encoder_ffn_expansion_size: int = 2
 
 
 @dataclass
@@ -105,9 +116,10 @@ class Model:
             # because the reference's version-5 model ignores them too -- a checkpoint that sets one runs with the same
             # semantics there as here:
             #   hf, interleave, logit_normalization, use_segmented_attention_mask, use_sliding_attention_mask: never read by
-            #     models/base.py / models/ar_nar.py / models/arch/llama.py (the attention-mask switches belong to base_v2.py);
+            #     models/base.py / models/ar_nar.py / models/arch/llama.py (the attention-mask switches belong to base_v2.py:
+            #     kept as fields for the version >= 7 model, which refuses them);
             #   tie_classifier_to_embedding, audio_embedding_mode, monolithic_audio_encoder: read into locals of
-            #     Base.__init__ (models/base.py:368-369, :381) and not used again;
+            #     Base.__init__ (models/base.py:368-369, :381) and not used again (version >= 7 reads the last one);
             #   predict_causally: training only (models/base.py:1033 calc_loss, models/ar_nar.py:182 forward_train);
             #   kv_heads: models/base.py:478 hard-wires num_key_value_heads = n_heads; size.embed_dim: a property of the
             #     dataclass only (config.py:472-476).

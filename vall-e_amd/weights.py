@@ -40,8 +40,71 @@ def classifier_layout(cfg: Model):
     return names, emb_tokens, cls_names, cls_tokens
 
 
+def state_dict_spec_v2(cfg: Model) -> "OrderedDict[str, tuple]":
+    """The version >= 7 model (vall_e/models/base_v2.py:412-469, :499; names listed by instantiating the reference):
+    plain tables, two AudioEncoders (per-level tables of token_dim = d_model, level position embedding, level weights,
+    LayerNorm, a residual FFN), the AudioDecoder (per level: LayerNorm, FFN, head), three auxiliary heads, the llama stack
+    WITHOUT its final norm (per_level_normalization moves it into the decoder, base_v2.py:495)."""
+    d, ff, L = cfg.dim, cfg.dim * cfg.ffn, cfg.resp_levels
+    e = cfg.experimental
+    spec = OrderedDict()
+    spec["sep"] = (d,)
+    spec["len_emb"] = (d,)
+    spec["phn_emb.weight"] = (cfg.phoneme_tokens, d)
+    spec["text_emb.weight"] = (cfg.text_tokens, d)
+    if cfg.langs > 0:
+        spec["langs_emb.weight"] = (cfg.langs, d)
+    if cfg.tasks > 0:
+        spec["tasks_emb.weight"] = (cfg.tasks, d)
+    if cfg.tones > 0:
+        spec["tones_emb.weight"] = (cfg.tones, d)
+    for name, n in (("proms_emb", cfg.audio_tokens), ("resps_emb", cfg.audio_tokens + 2)):      # (+ stop and mask token)
+        spec[f"{name}.pos_embedding"] = (1, L, d)
+        spec[f"{name}.level_weights"] = (L,)
+        for l in range(L):
+            spec[f"{name}.embs.{l}.weight"] = (n, d)
+        spec[f"{name}.norm.weight"] = (d,)
+        spec[f"{name}.norm.bias"] = (d,)
+        h = d * e.audio_encoder_ffn_expansion_size
+        spec[f"{name}.proj.0.weight"] = (h, d)
+        spec[f"{name}.proj.0.bias"] = (h,)
+        spec[f"{name}.proj.2.weight"] = (d, h)
+        spec[f"{name}.proj.2.bias"] = (d,)
+    h = d * e.audio_decoder_ffn_expansion_size
+    for l in range(L):
+        p = f"audio_decoder.head.{l}."
+        spec[p + "0.weight"] = (d,)
+        spec[p + "0.bias"] = (d,)
+        spec[p + "1.weight"] = (h, d)
+        spec[p + "1.bias"] = (h,)
+        spec[p + "3.weight"] = (d, h)
+        spec[p + "3.bias"] = (d,)
+        spec[p + "4.weight"] = (cfg.audio_tokens + 1, d)
+        spec[p + "4.bias"] = (cfg.audio_tokens + 1,)
+    n_len = 50 if e.len_use_logits else 1
+    for name, n in (("len_decoder", n_len), ("phn_decoder", cfg.phoneme_tokens), ("text_decoder", cfg.text_tokens)):
+        spec[f"{name}.head.weight"] = (n, d)
+        spec[f"{name}.head.bias"] = (n,)
+    for l in range(cfg.layers):
+        p = f"model.layers.{l}."
+        spec[p + "self_attn.q_proj.weight"] = (d, d)
+        spec[p + "self_attn.k_proj.weight"] = (d, d)
+        spec[p + "self_attn.v_proj.weight"] = (d, d)
+        spec[p + "self_attn.o_proj.weight"] = (d, d)
+        spec[p + "mlp.gate_proj.weight"] = (ff, d)
+        spec[p + "mlp.up_proj.weight"] = (ff, d)
+        spec[p + "mlp.down_proj.weight"] = (d, ff)
+        spec[p + "input_layernorm.weight"] = (d,)
+        spec[p + "post_attention_layernorm.weight"] = (d,)
+    if not e.per_level_normalization:
+        spec["model.norm.weight"] = (d,)
+    return spec
+
+
 def state_dict_spec(cfg: Model) -> "OrderedDict[str, tuple]":
     """Ordered {name: shape} exactly as ``reference_model.state_dict()`` yields it."""
+    if cfg.version >= 7:
+        return state_dict_spec_v2(cfg)
     d = cfg.dim
     ff = cfg.dim * cfg.ffn
     L = cfg.resp_levels
@@ -86,6 +149,19 @@ def state_dict_spec(cfg: Model) -> "OrderedDict[str, tuple]":
 def _kind(name: str) -> str:
     if name.endswith("layernorm.weight") or name == "model.norm.weight":
         return "norm"
+    # version >= 7 names (base_v2.py): encoder / decoder LayerNorms, FFNs, heads, level tables
+    if name.endswith("_emb.norm.weight") or (name.startswith("audio_decoder.head.") and name.endswith(".0.weight")):
+        return "norm"
+    if name.endswith("_emb.norm.bias") or (name.startswith("audio_decoder.head.") and name.endswith(".0.bias")):
+        return "head_bias"
+    if name.endswith(".pos_embedding"):
+        return "pos"
+    if name.endswith(".level_weights"):
+        return "level_weights"
+    if "_emb.proj." in name or name.startswith("audio_decoder.head.") or "_decoder.head." in name:
+        if name.endswith(".bias"):
+            return "head_bias"
+        return "head" if (name.endswith(".4.weight") or "_decoder.head." in name) else "ffn"
     if name.startswith("classifiers.") and name.endswith(".bias"):
         return "head_bias"
     if name.startswith("classifiers."):
@@ -118,9 +194,18 @@ def synth_state_dict(cfg: Model, seed: int = 1234, stop_bias: float | None = Non
             x = head_std * x
         elif kind == "head_bias":
             x = 0.1 * x
+        elif kind == "ffn":
+            x = 2.0 * linear_std * x
+        elif kind == "pos":
+            x = 0.3 * x
+        elif kind == "level_weights":
+            x = 1.0 / shape[0] ** 0.5 + 0.5 * x
         out[name] = x
     if stop_bias is not None and "classifiers.proj.0.bias" in out:
         out["classifiers.proj.0.bias"][cfg.audio_tokens] = stop_bias
+    if stop_bias is not None and cfg.version >= 7:
+        for l in range(cfg.resp_levels):
+            out[f"audio_decoder.head.{l}.4.bias"][cfg.audio_tokens] = stop_bias
     return out
 
 
