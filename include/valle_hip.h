@@ -57,6 +57,8 @@ extern "C" {
 #define VALLE_EPI_RESID  1      /* C = resid + A.W^T                                           */
 #define VALLE_EPI_GEGLU  2      /* C[:, j] = gelu_erf(acc[:, 2j]) * acc[:, 2j+1]  (N/2 columns) */
 #define VALLE_EPI_F32OUT 3      /* C (fp32) = A.W^T + bias, whatever `dtype` is                */
+#define VALLE_EPI_GELU   6      /* C = gelu_erf(A.W^T + bias): nn.Linear + nn.GELU of the version >= 7 encoder / decoder FFNs  */
+#define VALLE_EPI_RESID_BIAS 7  /* C = resid + (A.W^T + bias): the residual FFN of the AudioEncoder (models/base_v2.py:149)    */
 
 const char* valle_last_error(void);
 int valle_version(void);
@@ -155,6 +157,8 @@ typedef struct {
     int    dry_allowed_length;      /* >= 2 makes the reference's loop a no-op; kept for fidelity   */
     int    filter_passes;           /* 0 / 1: top-k / top-p once; 2 reproduces NAR-len's second in-place pass
                                      * (only when min_p is off: min-p filters out of place, samplers.py:90)   */
+    int    score_unscaled;          /* != 0: the version >= 7 sampler's score (models/base_v2.py:1398-1410) -- softmax of the
+                                     * processed logits BEFORE the temperature, at the drawn token; 0: after it           */
 } valle_sample_params;
 
 /* Sampler chain on fp32 logits [rows][ld] (first `vocab` columns valid): repetition penalty
@@ -298,6 +302,43 @@ int valle_forward_dense(valle_model* m, const int32_t* emb_idx, const int32_t* p
                         const int32_t* cache_slot, const int32_t* cache_pos0,
                         const int32_t* out_rows, int n_out, int head, float* logits, int ld_logits,
                         void* hidden_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------- version >= 7 model ("v2": models/base_v2.py) ---- */
+
+/* nn.LayerNorm over the last dimension (with weight and bias, eps inside the square root): the AudioDecoder's per-level
+ * norm (models/base_v2.py:184).  x, w, b, out in dtype. */
+int valle_layernorm(const void* x, const void* w, const void* b, void* out, int rows, int d, float eps, int dtype, void* stream);
+
+/* First half of AudioEncoder.forward (models/base_v2.py:138-147) for n code frames of L <= 32 levels: out[(i * L + l)][:] =
+ * LayerNorm(table[row0[l] + codes[l * ld_codes + i]][:] + pos[l][:]) -- codes level-major int32 on the device, table = the
+ * concatenated embedding table (row0[l] = first row of level l's table, n_rows[l] = its row count: HOST arrays of L ints;
+ * a code outside its table is clamped into it), pos [L][d], norm weight / bias [d]; src_scratch: n * L int32 on the
+ * device (the gathered row ids). */
+int valle_v2_encode_rows(const void* table, const int32_t* row0_host, const int32_t* n_rows_host, int L, const int32_t* codes,
+                         int ld_codes, int n, const void* pos, const void* norm_w, const void* norm_b, void* out,
+                         int32_t* src_scratch, int d, float eps, int dtype, void* stream);
+
+/* Second half (models/base_v2.py:153-157): out[dst_rows[i]][:] = sum_l lw[l] * y[(i * L + l)][:] (lw = softmax of the level
+ * weights, fp32 [L] on the device; products rounded to dtype as the reference's elementwise multiply is); dst_rows == NULL:
+ * row i.  This is also how encoded frames are placed into their rows of the packed sequence. */
+int valle_v2_level_sum(const void* y, const float* lw, int L, int n, const int32_t* dst_rows, void* out, int d, int dtype,
+                       void* stream);
+
+/* Classifier-free guidance on (levels, rows, vocab) logits (samplers.py:177-191 with a 3-D input): for utterance i, level l
+ * and vocabulary column v, s = neg + (pos - neg) * strength over the rows [row_off[i], row_off[i+1]); with rescale > 0,
+ * s *= rescale * std_rows(pos) / std_rows(s) + (1 - rescale), std = the unbiased std over the ROWS of that column.
+ * pos / neg: [L][rows_total][ld] fp32, written in place into pos. */
+int valle_cfg_combine_cols(float* pos, const float* neg, int ld, int vocab, int L, int rows_total, const int32_t* row_off,
+                           int B, float strength, float rescale, void* stream);
+
+/* valle_forward_dense for a model whose embeddings are computed outside (the version >= 7 AudioEncoder): x_in [M][d] in
+ * dtype replaces the embedding gather, the stack runs as in valle_forward_dense, and hidden_out [n_out][d] receives the
+ * out_rows of the last layer's output -- normalised by the final RMSNorm when final_norm != 0, raw otherwise
+ * (per_level_normalization moves that norm into the decoder, models/base_v2.py:495).  No head is applied. */
+int valle_forward_layers(valle_model* m, const void* x_in, const int32_t* pos, const int32_t* cu_seqlens, int B, int M,
+                         int max_T, int causal, void* kcache, void* vcache, int cache_T, size_t cache_layer_stride,
+                         const int32_t* cache_slot, const int32_t* cache_pos0, const int32_t* out_rows, int n_out,
+                         int final_norm, void* hidden_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* valle_forward_dense that also returns the LAST layer's raw attention products of chosen rows: scores[r][h][j] =
  * q[score_rows[r]][h] . k[j][h] / sqrt(head_dim) for every row j of that row's utterance, fp32 [n_score][H][ld_scores]

@@ -104,11 +104,12 @@ def get_ref_model(kind, dtype=torch.float32, **synth_kw):
     mcfg = {"full": vcfg.repo_default_model, "tiny": vcfg.tiny_model, "tiny_len": vcfg.tiny_len_model,
             "tiny_nc": vcfg.tiny_nc_model, "tiny_tone": vcfg.tiny_tone_model, "tiny_upi": vcfg.tiny_upi_model, "tiny_nobias": vcfg.tiny_nobias_model, "tiny_nc_upi": vcfg.tiny_nc_upi_model, "tiny_nosum": vcfg.tiny_nosum_model, "tiny_sumprom": vcfg.tiny_sumprom_model,
             "half2": lambda: vcfg.tiny_model(dim=512, heads=8), "s075_2": lambda: vcfg.tiny_model(dim=768, heads=12),
-            "tiny_v2": vcfg.tiny_v2_model, "tiny_v2_nc": vcfg.tiny_v2_nc_model}[kind]()
+            "tiny_v2": vcfg.tiny_v2_model, "tiny_v2_nc": vcfg.tiny_v2_nc_model, "tiny_v2_len": vcfg.tiny_v2_len_model}[kind]()
     if mcfg.version >= 7:
         model = rh.build_reference_model(size=mcfg.size, capabilities=list(mcfg.capabilities), version=mcfg.version,
                                          noncausal_masks=mcfg.experimental.noncausal_masks,
-                                         unified_position_ids=mcfg.experimental.unified_position_ids)
+                                         unified_position_ids=mcfg.experimental.unified_position_ids,
+                                         len_use_logits=mcfg.experimental.len_use_logits)
         assert type(model).__name__ == "AR_NAR_V2"
         sd = synth_state_dict(mcfg, synth_kw.pop("weight_seed", WEIGHT_SEED), **synth_kw)
         model.load_state_dict(sd, strict=True)
@@ -1059,15 +1060,56 @@ def scen_tiny_v2():
         print(f"  [{name}] codes {codes[0].tolist()[:2]} min top-2 gap {min(gaps):.3e}")
         save(name, **o)
 
-    for name, kind in (("tiny_v2_narlen", "tiny_v2"), ("tiny_v2_nc_narlen", "tiny_v2_nc")):
+    # The demasking loop masks the k lowest scores per level through torch.topk (ar_nar_v2.py:300).  Where the k-th and the
+    # (k+1)-th lowest score of a level are EQUAL, which of them is masked is an internal of torch.topk's implementation
+    # (CPU: libstdc++ nth_element), not of the algorithm; every golden records how many (step, utterance, level) cuts fell on
+    # such a tie.  Under the default top-n-sigma filter the tiny model leaves one candidate per row in places (probability
+    # exactly 1.0, hence ties); the "_noties" goldens switch it off (top_no = 0) and have none.
+    cuts = []
+    orig_topk = torch.Tensor.topk
+    def counting_topk(self, k, dim=-1, largest=True, sorted=True):
+        if not largest and self.dim() == 2 and k < self.shape[0]:
+            srt = self.sort(dim=0).values
+            cuts.append(int((srt[k - 1] == srt[k]).sum()))
+        return orig_topk(self, k, dim=dim, largest=largest, sorted=sorted)
+    for name, kind, kw in (("tiny_v2_narlen", "tiny_v2", {}), ("tiny_v2_nc_narlen", "tiny_v2_nc", {}),
+                           ("tiny_v2_narlen_noties", "tiny_v2", {"top_no": 0.0}), ("tiny_v2_nc_narlen_noties", "tiny_v2_nc", {"top_no": 0.0}),
+                           ("tiny_v2_narlen_masked_only", "tiny_v2", {"top_no": 0.0, "sampling_scores_masked_only": True, "max_steps": 6})):
         model, mcfg = get_ref_model(kind)
         lens = [9, 12]
-        codes = run_narlen(model, phns, proms, langs, lens, max_steps=4, temperature=0.0)
+        kw = dict(kw)
+        steps = kw.pop("max_steps", 4)
+        cuts.clear()
+        torch.Tensor.topk = counting_topk
+        try:
+            codes = run_narlen(model, phns, proms, langs, lens, max_steps=steps, temperature=0.0, **kw)
+        finally:
+            torch.Tensor.topk = orig_topk
         o = input_arrays(phns, proms, langs)
         o.update(pack_list("codes", codes))
-        o["lens"], o["max_steps"] = np.array(lens), np.int64(4)
-        print(f"  [{name}] {[tuple(c.shape) for c in codes]} {codes[0][:2].tolist()}")
+        o["lens"], o["max_steps"], o["tied_cuts"] = np.array(lens), np.int64(steps), np.int64(sum(cuts))
+        for k_, v_ in kw.items():
+            o[f"kw_{k_}"] = np.float64(v_)
+        print(f"  [{name}] {[tuple(c.shape) for c in codes]} {codes[0][:2].tolist()} tied cuts {sum(cuts)}")
         save(name, **o)
+
+    # duration prediction (ar_nar_v2.py:374-431, base_v2.py:1296-1308) with the 5-digit head; with the dataclass default
+    # (len_use_logits = False: one float) the reference's own pass dies reshaping (T, 1) to (-1, 5, 10) (base_v2.py:1283)
+    model, mcfg = get_ref_model("tiny_v2_len")
+    ref.cfg.dataset._frames_per_second = 75
+    with torch.inference_mode():
+        frames = model(task_list=["len"] * 2, **to_model_inputs(phns, proms, langs), disable_tqdm=True)
+    o = input_arrays(phns, proms, langs)
+    o["frames"] = np.array([int(f) for f in frames])
+    print(f"  [tiny_v2_len] frames {frames}")
+    save("tiny_v2_len", **o)
+    model, mcfg = get_ref_model("tiny_v2")
+    try:
+        with torch.inference_mode():
+            model(task_list=["len"] * 2, **to_model_inputs(phns, proms, langs), disable_tqdm=True)
+        print("  [tiny_v2 len, float head] ran")
+    except Exception as e:                                                   # recorded in DESIGN.md, not a fixture
+        print(f"  [tiny_v2 len, float head] {type(e).__name__}: {str(e)[:120]}")
 
 
 def scen_full_b3():

@@ -126,7 +126,10 @@ class OracleV2(Oracle):
         return logits
 
     # -- AR_NAR_V2.forward_nar_masked (ar_nar_v2.py:207-372) ---------------------------------------
-    def nar_masked_v2(self, phns, proms, langs, lens, **kw):
+    def nar_masked_v2(self, phns, proms, langs, lens, tie_rule="topk", **kw):
+        """tie_rule: which positions are masked when the k-th and (k+1)-th lowest scores of a level are equal -- "topk":
+        whatever torch.topk returns (the reference's behaviour on this torch build: an internal of its partial sort);
+        "lowest_index": the lower index first (a stable sort), the rule valle_mask_lowest implements."""
         kw = convert_kwargs(dict(kw), "ar_")
         lens = [clamp(int(l), kw.pop("min_duration", 1), kw.pop("max_duration", 500)) for l in lens]
         max_steps = kw.get("max_steps", 25)
@@ -147,7 +150,11 @@ class OracleV2(Oracle):
         for step, t in enumerate(torch.linspace(start, end, max_steps)):
             noise_p = math.cos(t * math.pi * 0.5)
             mask_p = noise_p + (1.0 / (max_steps * 2) if remask else 0)
-            idx = [s.topk(clamp(int(mask_p * n), 1, n - step), dim=0, largest=False).indices for s, n in zip(scores, lens)]
+            ks = [clamp(int(mask_p * n), 1, n - step) for n in lens]
+            if tie_rule == "topk":
+                idx = [s.topk(k, dim=0, largest=False).indices for s, k in zip(scores, ks)]
+            else:
+                idx = [s.sort(dim=0, stable=True).indices[:k] for s, k in zip(scores, ks)]
             resps = [torch.stack([r[:, l].scatter(0, i.t()[l], self.mask_token) for l in range(Lv)], dim=-1) for r, i in zip(resps, idx)]
             is_masked = [r == self.mask_token for r in resps]
             temp = temperature * (1.0 - float(t)) if annealed else temperature
@@ -161,6 +168,29 @@ class OracleV2(Oracle):
             if flatten:
                 scores = [s.mean(dim=0).repeat(s.shape[0], 1) for s in scores]
         return resps
+
+    # -- AR_NAR_V2.forward_len (ar_nar_v2.py:374-431; base_v2.py:652-678, :1296-1308) with len_use_logits ------------
+    def len_v2(self, phns, proms, langs, frames_per_second=75):
+        w, out = self.w, []
+        for i in range(len(phns)):
+            segs = [w["phn_emb.weight"][phns[i].long()]]
+            if langs is not None:
+                segs.append(w["langs_emb.weight"][langs[i].long()])
+            if proms is not None:
+                segs.append(self.audio_encode("proms_emb", proms[i]))
+            segs.append(w["len_emb"][None])
+            x = segs[0]
+            for e in segs[1:]:
+                x = torch.cat((x, w["sep"][None], e), dim=0)
+            pos = torch.cat([torch.arange(e.shape[0] + (0 if j == len(segs) - 1 else 1), dtype=torch.int32) for j, e in enumerate(segs)])[: x.shape[0]]
+            if self.unified_pos:
+                pos = torch.arange(x.shape[0], dtype=torch.int32)
+            causal = not self.cfg.experimental.noncausal_masks               # "len" is not among the causal levels (base_v2.py:1182)
+            hid = self.stack(x, pos, [x.shape[0]], causal=[causal], final_norm=not self.cfg.experimental.per_level_normalization)
+            lg = F.linear(hid[-1], w["len_decoder.head.weight"], w["len_decoder.head.bias"])
+            digits = lg.view(5, 10).argmax(dim=-1)
+            out.append(int(int("".join(str(int(t)) for t in digits)) / frames_per_second * frames_per_second))
+        return out
 
     # -- AR_NAR_V2.forward_ar (ar_nar_v2.py:433-589): 8 codes per step from the newest row ---------
     def ar_v2(self, phns, proms, langs, *, max_duration=500, return_logits=False, **kw):

@@ -48,7 +48,7 @@ def model_cfg(kind):
     return {"full": vcfg.repo_default_model, "tiny": vcfg.tiny_model, "tiny_len": vcfg.tiny_len_model,
             "tiny_nc": vcfg.tiny_nc_model, "tiny_tone": vcfg.tiny_tone_model, "tiny_upi": vcfg.tiny_upi_model, "tiny_nobias": vcfg.tiny_nobias_model, "tiny_nc_upi": vcfg.tiny_nc_upi_model, "tiny_nosum": vcfg.tiny_nosum_model, "tiny_sumprom": vcfg.tiny_sumprom_model,
             "half2": lambda: vcfg.tiny_model(dim=512, heads=8), "s075_2": lambda: vcfg.tiny_model(dim=768, heads=12),
-            "tiny_v2": vcfg.tiny_v2_model, "tiny_v2_nc": vcfg.tiny_v2_nc_model}[kind]()
+            "tiny_v2": vcfg.tiny_v2_model, "tiny_v2_nc": vcfg.tiny_v2_nc_model, "tiny_v2_len": vcfg.tiny_v2_len_model}[kind]()
 
 
 def synth_weights(kind, **kw):

@@ -85,3 +85,12 @@ def tiny_v2_nc_model(**kw) -> Model:
     m = tiny_v2_model(**kw)
     m.experimental.noncausal_masks = True
     return m
+
+
+def tiny_v2_len_model(**kw) -> Model:
+    """``tiny_v2_model`` with ``len_use_logits``: the duration head predicts 5 digits (base_v2.py:467, :1302-1306).  With the
+    dataclass default (a single float) the reference's own pass fails reshaping the head's (T, 1) output to (-1, 5, 10)
+    (base_v2.py:1283) unless T is a multiple of 50."""
+    m = tiny_v2_model(**kw)
+    m.experimental.len_use_logits = True
+    return m

@@ -561,9 +561,25 @@ def test_tiny_v2_ar_and_narlen():
     out = make_oracle_v2("tiny_v2").ar_v2(phns, proms, langs, max_duration=int(z["steps"]), temperature=0.0)
     for b in range(2):
         np.testing.assert_array_equal(out[b].numpy(), z[f"ar_codes_{b}"])
-    for name, kind in (("tiny_v2_narlen", "tiny_v2"), ("tiny_v2_nc_narlen", "tiny_v2_nc")):
+    for name, kind in (("tiny_v2_narlen", "tiny_v2"), ("tiny_v2_nc_narlen", "tiny_v2_nc"), ("tiny_v2_narlen_noties", "tiny_v2"),
+                       ("tiny_v2_nc_narlen_noties", "tiny_v2_nc"), ("tiny_v2_narlen_masked_only", "tiny_v2")):
         z = load_golden(name)
         phns, proms, langs = golden_inputs(z)
-        out = make_oracle_v2(kind).nar_masked_v2(phns, proms, langs, [int(x) for x in z["lens"]], max_steps=int(z["max_steps"]), temperature=0.0)
+        kw = {k[3:]: (bool(z[k]) if "scores" in k else float(z[k])) for k in z if k.startswith("kw_")}
+        lens = [int(x) for x in z["lens"]]
+        o = make_oracle_v2(kind)
+        out = o.nar_masked_v2(phns, proms, langs, lens, max_steps=int(z["max_steps"]), temperature=0.0, **kw)
         for b in range(2):
             np.testing.assert_array_equal(out[b].numpy(), z[f"codes_{b}"])
+        if int(z["tied_cuts"]) == 0:
+            # no cut of the masking falls on tied scores: the result does not depend on torch.topk's order among ties
+            out = o.nar_masked_v2(phns, proms, langs, lens, max_steps=int(z["max_steps"]), temperature=0.0, tie_rule="lowest_index", **kw)
+            for b in range(2):
+                np.testing.assert_array_equal(out[b].numpy(), z[f"codes_{b}"])
+
+
+def test_tiny_v2_len():
+    """Duration prediction of the version-7 model with the 5-digit head (ar_nar_v2.py:374-431): frames == the reference's."""
+    z = load_golden("tiny_v2_len")
+    phns, proms, langs = golden_inputs(z)
+    assert make_oracle_v2("tiny_v2_len").len_v2(phns, proms, langs) == [int(x) for x in z["frames"]]

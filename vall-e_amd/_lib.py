@@ -14,6 +14,7 @@ import torch
 
 F32, BF16 = 0, 1
 EPI_STORE, EPI_RESID, EPI_GEGLU, EPI_F32OUT = 0, 1, 2, 3
+EPI_GELU, EPI_RESID_BIAS = 6, 7
 
 _LIB_PATH = Path(__file__).resolve().parent / "libvalle_hip.so"
 _lib = None
@@ -29,6 +30,7 @@ class SampleParams(C.Structure):
         ("seed", C.c_uint64), ("offset", C.c_uint64),
         ("temperature64", C.c_double), ("min_temperature64", C.c_double),
         ("dry_multiplier", C.c_double), ("dry_base", C.c_double), ("dry_allowed_length", C.c_int), ("filter_passes", C.c_int),
+        ("score_unscaled", C.c_int),
     ]
 
 
@@ -107,6 +109,14 @@ SIGNATURES = {
     "valle_entropix_pick": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_int, c_void_p, c_int, C.c_uint64, C.c_uint64, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p]),
+    "valle_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
+    "valle_v2_encode_rows": (c_int, [c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), c_int, c_void_p, c_int, c_int, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]),
+    "valle_v2_level_sum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "valle_cfg_combine_cols": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_float, c_void_p]),
+    "valle_forward_layers": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                     c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p,
+                                     c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "valle_decode_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "valle_ar_decode": (c_int, [c_void_p, C.POINTER(ARState), C.POINTER(SampleParams), c_int, c_void_p, c_int,
                                 c_void_p, c_size_t, c_void_p]),

@@ -91,6 +91,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[NI][MJ], int nw0, int
                         const vec4 rr = *reinterpret_cast<const vec4*>(resid + (size_t)m * ldc + nb);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(to_f32<T>(rr[r]) + to_f32<T>(from_f32<T>(v[r])));
+                    } else if constexpr (EPI == VALLE_EPI_RESID_BIAS) {
+                        const vec4 rr = *reinterpret_cast<const vec4*>(resid + (size_t)m * ldc + nb);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(to_f32<T>(rr[r]) + to_f32<T>(from_f32<T>(v[r] + to_f32<T>(bt[nb + r]))));
+                    } else if constexpr (EPI == VALLE_EPI_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(gelu_erf(to_f32<T>(from_f32<T>(v[r] + to_f32<T>(bt[nb + r])))));
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r] + (bt ? to_f32<T>(bt[nb + r]) : 0.f));
@@ -102,6 +109,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[NI][MJ], int nw0, int
                         if (nb + r >= N) continue;
                         float o = v[r];
                         if constexpr (EPI == VALLE_EPI_RESID) o = to_f32<T>(resid[(size_t)m * ldc + nb + r]) + to_f32<T>(from_f32<T>(o));
+                        else if constexpr (EPI == VALLE_EPI_RESID_BIAS) o = to_f32<T>(resid[(size_t)m * ldc + nb + r]) + to_f32<T>(from_f32<T>(o + to_f32<T>(bt[nb + r])));
+                        else if constexpr (EPI == VALLE_EPI_GELU) o = gelu_erf(to_f32<T>(from_f32<T>(o + to_f32<T>(bt[nb + r]))));
                         else if (bt) o += to_f32<T>(bt[nb + r]);
                         C[(size_t)m * ldc + nb + r] = from_f32<T>(o);
                     }
@@ -611,6 +620,7 @@ static int gemm_glds_dispatch(const void* A, const void* W, const void* bias, co
 #define GLDS_CASE(E) case E: gemm_glds_bf16_kernel<E><<<grid, 256, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc); break;
     switch (epi) {
         GLDS_CASE(VALLE_EPI_STORE) GLDS_CASE(VALLE_EPI_RESID) GLDS_CASE(VALLE_EPI_GEGLU) GLDS_CASE(VALLE_EPI_F32OUT)
+        GLDS_CASE(VALLE_EPI_GELU) GLDS_CASE(VALLE_EPI_RESID_BIAS)
         default: valle_set_error("valle_gemm: unknown epilogue %d", epi); return VALLE_E_ARG;
     }
 #undef GLDS_CASE
@@ -674,6 +684,8 @@ static int gemm_dispatch(const void* A, const void* W, const void* bias, const v
         case VALLE_EPI_RESID:  gemm_nt_kernel<T, VALLE_EPI_RESID><<<grid, 256, 0, s>>>((const T*)A, (const T*)W, bias, (const T*)resid, C, M, N, K, ldc); break;
         case VALLE_EPI_GEGLU:  gemm_nt_kernel<T, VALLE_EPI_GEGLU><<<grid, 256, 0, s>>>((const T*)A, (const T*)W, bias, (const T*)resid, C, M, N, K, ldc); break;
         case VALLE_EPI_F32OUT: gemm_nt_kernel<T, VALLE_EPI_F32OUT><<<grid, 256, 0, s>>>((const T*)A, (const T*)W, bias, (const T*)resid, C, M, N, K, ldc); break;
+        case VALLE_EPI_GELU:   gemm_nt_kernel<T, VALLE_EPI_GELU><<<grid, 256, 0, s>>>((const T*)A, (const T*)W, bias, (const T*)resid, C, M, N, K, ldc); break;
+        case VALLE_EPI_RESID_BIAS: gemm_nt_kernel<T, VALLE_EPI_RESID_BIAS><<<grid, 256, 0, s>>>((const T*)A, (const T*)W, bias, (const T*)resid, C, M, N, K, ldc); break;
         default: valle_set_error("valle_gemm: unknown epilogue %d", epi); return VALLE_E_ARG;
     }
     VALLE_LAUNCH_CHECK();
@@ -684,7 +696,8 @@ extern "C" int valle_gemm(const void* A, const void* W, const void* bias, const 
                           int M, int N, int K, int ldc, int epilogue, int dtype, void* stream) {
     VALLE_REQUIRE(A && W && C, VALLE_E_ARG, "valle_gemm: null pointer");
     VALLE_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 32 == 0, VALLE_E_ARG, "valle_gemm: M=%d N=%d K=%d (K must be a multiple of 32)", M, N, K);
-    VALLE_REQUIRE(epilogue != VALLE_EPI_RESID || resid, VALLE_E_ARG, "valle_gemm: EPI_RESID needs resid");
+    VALLE_REQUIRE((epilogue != VALLE_EPI_RESID && epilogue != VALLE_EPI_RESID_BIAS) || resid, VALLE_E_ARG, "valle_gemm: EPI_RESID needs resid");
+    VALLE_REQUIRE((epilogue != VALLE_EPI_GELU && epilogue != VALLE_EPI_RESID_BIAS) || bias, VALLE_E_ARG, "valle_gemm: EPI_GELU / EPI_RESID_BIAS need a bias");
     VALLE_REQUIRE(epilogue != VALLE_EPI_GEGLU || (N % 4 == 0 && ldc % 2 == 0), VALLE_E_ARG, "valle_gemm: EPI_GEGLU needs N %% 4 == 0");
     VALLE_REQUIRE(ldc >= (epilogue == VALLE_EPI_GEGLU ? N / 2 : N), VALLE_E_ARG, "valle_gemm: ldc %d too small", ldc);
     if (M == 0) return VALLE_OK;

@@ -173,8 +173,9 @@ static int forward_dense_impl(valle_model* m, const int32_t* emb_idx, const int3
                               const int32_t* cache_slot, const int32_t* cache_pos0,
                               const int32_t* out_rows, int n_out, int head, float* logits, int ld_logits,
                               void* hidden_out, void* workspace, size_t workspace_bytes, void* stream,
-                              const int32_t* score_rows, int n_score, float* scores, int ld_scores) {
-    VALLE_REQUIRE(m && emb_idx && pos && cu_seqlens && workspace, VALLE_E_ARG, "valle_forward_dense: null pointer");
+                              const int32_t* score_rows, int n_score, float* scores, int ld_scores,
+                              const void* x_in = nullptr, int final_norm = 1) {
+    VALLE_REQUIRE(m && (emb_idx || x_in) && pos && cu_seqlens && workspace, VALLE_E_ARG, "valle_forward_dense: null pointer");
     VALLE_REQUIRE(B > 0 && M > 0, VALLE_E_ARG, "valle_forward_dense: empty batch (B=%d, M=%d)", B, M);
     VALLE_REQUIRE(n_out == 0 || out_rows, VALLE_E_ARG, "valle_forward_dense: out_rows missing");
     // the last layer runs its output projection and MLP on the n_out gathered rows inside buffers carved for M rows
@@ -196,7 +197,8 @@ static int forward_dense_impl(valle_model* m, const int32_t* emb_idx, const int3
     hipStream_t s = (hipStream_t)stream;
     int rc;
 #define RUN(call) do { rc = (call); if (rc != VALLE_OK) return rc; } while (0)
-    RUN(valle_embed_sum(m->emb, emb_idx, x, M, d, dt, s));
+    if (x_in) VALLE_HIP_CHECK(hipMemcpyAsync(x, x_in, (size_t)M * d * es, hipMemcpyDeviceToDevice, s));   // the stack works in place
+    else RUN(valle_embed_sum(m->emb, emb_idx, x, M, d, dt, s));
     for (int l = 0; l < c.n_layers; ++l) {
         const valle_layer_weights& w = m->layers[l];
         // bf16 with folded weight copies: the two RMSNorms ride in the q/k/v and gate/up GEMMs (valle_gemm_normed)
@@ -242,7 +244,8 @@ static int forward_dense_impl(valle_model* m, const int32_t* emb_idx, const int3
     }
     if (n_out > 0) {                                       // sel = the requested rows of the last layer's output
         void* dst = hidden_out ? hidden_out : seln;
-        RUN(valle_rmsnorm(sel, m->final_norm, dst, n_out, d, c.rms_eps, dt, s));
+        if (final_norm) RUN(valle_rmsnorm(sel, m->final_norm, dst, n_out, d, c.rms_eps, dt, s));
+        else VALLE_HIP_CHECK(hipMemcpyAsync(dst, sel, (size_t)n_out * d * es, hipMemcpyDeviceToDevice, s));
         if (logits)
             RUN(valle_gemm(dst, m->head_w[head], m->head_b[head], nullptr, logits, n_out, m->head_n[head], d, ld_logits,
                            VALLE_EPI_F32OUT, dt, s));
@@ -274,6 +277,19 @@ extern "C" int valle_forward_dense_scores(valle_model* m, const int32_t* emb_idx
     return forward_dense_impl(m, emb_idx, pos, cu_seqlens, B, M, max_T, causal, kcache, vcache, cache_T, cache_layer_stride,
                               cache_slot, cache_pos0, out_rows, n_out, head, logits, ld_logits, hidden_out, workspace,
                               workspace_bytes, stream, score_rows, n_score, scores, ld_scores);
+}
+
+// The stack alone, on embeddings computed outside (version >= 7: the AudioEncoder's rows, models/base_v2.py:725-799), with
+// or without the final RMSNorm (per_level_normalization moves it into the AudioDecoder, base_v2.py:495); no head.
+extern "C" int valle_forward_layers(valle_model* m, const void* x_in, const int32_t* pos, const int32_t* cu_seqlens, int B,
+                                    int M, int max_T, int causal, void* kcache, void* vcache, int cache_T,
+                                    size_t cache_layer_stride, const int32_t* cache_slot, const int32_t* cache_pos0,
+                                    const int32_t* out_rows, int n_out, int final_norm, void* hidden_out, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    VALLE_REQUIRE(x_in && hidden_out && n_out > 0, VALLE_E_ARG, "valle_forward_layers: x_in, hidden_out and out_rows are required");
+    return forward_dense_impl(m, nullptr, pos, cu_seqlens, B, M, max_T, causal, kcache, vcache, cache_T, cache_layer_stride,
+                              cache_slot, cache_pos0, out_rows, n_out, 0, nullptr, 0, hidden_out, workspace, workspace_bytes,
+                              stream, nullptr, 0, nullptr, 0, x_in, final_norm);
 }
 
 extern "C" size_t valle_decode_workspace_bytes(const valle_model* m, int B) {

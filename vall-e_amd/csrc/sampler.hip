@@ -445,9 +445,17 @@ __global__ __launch_bounds__(SAMP_THREADS) void sample_kernel(SampleArgs a) {
         __syncthreads();
         tok = s_flag;
     }
+    // version >= 7 sampler (models/base_v2.py:1398-1410): the score is the softmax of the processed logits BEFORE the
+    // temperature, at the token drawn from logits / temperature
+    float se_unscaled = 0.f;
+    const bool unscaled = a.p.score_unscaled != 0 && a.p.temperature > 0.0f && a.p.temperature64 == a.p.min_temperature64 && a.mirostat == nullptr;
+    if (unscaled) {
+        for (int v = tid; v < V; v += SAMP_THREADS) se_unscaled += expf((vals[v] - mx) * a.p.temperature);
+        se_unscaled = block_reduce_sum(se_unscaled, red);
+    }
     if (tid == 0) {
         a.ids[row] = tok;
-        const float sc = expf(vals[tok] - mx) / se;
+        const float sc = unscaled ? expf((vals[tok] - mx) * a.p.temperature) / se_unscaled : expf(vals[tok] - mx) / se;
         if (a.scores) a.scores[row] = sc;
         if (a.seq != nullptr && !(a.early_exit && a.stopped[item])) {  // fused AR append (models/ar_nar.py:837-842)
             const int n = a.seq_len[item];

@@ -596,7 +596,7 @@ class Base:
     def sample_params(self, *, temperature=1.0, min_temperature=-1.0, top_k=-100, top_p=1.0, min_p=0.0,
                       repetition_penalty=1.0, repetition_penalty_decay=0.0, length_penalty=0.0, top_no=1.0,
                       rep_pen_passes=1, seed=0, offset=0, dry_multiplier=0.0, dry_base=1.75, dry_allowed_length=2,
-                      filter_passes=1, **other) -> L.SampleParams:
+                      filter_passes=1, score_unscaled=0, **other) -> L.SampleParams:
         """Base.sample's kwargs (base.py:1288-1309) -> the C struct.  Samplers outside the built
         chain raise instead of being silently ignored."""
         for k in UNSUPPORTED_SAMPLERS:
@@ -617,7 +617,7 @@ class Base:
                               float(repetition_penalty), float(repetition_penalty_decay), float(length_penalty),
                               int(self.stop_token), int(rep_pen_passes), int(seed), int(offset),
                               float(temperature), float(min_temperature), float(dry_multiplier), float(dry_base),
-                              int(dry_allowed_length), int(filter_passes))
+                              int(dry_allowed_length), int(filter_passes), int(score_unscaled))
 
     # ------------------------------------------------------------------------------ entropix
     # samplers.py:364-414 (EntropixSamplerConfig)
