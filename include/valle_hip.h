@@ -334,11 +334,15 @@ int valle_cfg_combine_cols(float* pos, const float* neg, int ld, int vocab, int 
 /* valle_forward_dense for a model whose embeddings are computed outside (the version >= 7 AudioEncoder): x_in [M][d] in
  * dtype replaces the embedding gather, the stack runs as in valle_forward_dense, and hidden_out [n_out][d] receives the
  * out_rows of the last layer's output -- normalised by the final RMSNorm when final_norm != 0, raw otherwise
- * (per_level_normalization moves that norm into the decoder, models/base_v2.py:495).  No head is applied. */
+ * (per_level_normalization moves that norm into the decoder, models/base_v2.py:495).  No head is applied.
+ * kv_lens (optional, [B], 1 <= kv_lens[b] <= rows of b): only the first kv_lens[b] rows of utterance b are keys; the rows
+ * behind them are queries alone -- the padding rows of the reference's right-padded batch, whose last one the version >= 7
+ * duration head reads (models/base_v2.py:1298-1300: logit[..., -1, :] of the PADDED batch). */
 int valle_forward_layers(valle_model* m, const void* x_in, const int32_t* pos, const int32_t* cu_seqlens, int B, int M,
                          int max_T, int causal, void* kcache, void* vcache, int cache_T, size_t cache_layer_stride,
                          const int32_t* cache_slot, const int32_t* cache_pos0, const int32_t* out_rows, int n_out,
-                         int final_norm, void* hidden_out, void* workspace, size_t workspace_bytes, void* stream);
+                         int final_norm, const int32_t* kv_lens, void* hidden_out, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* valle_forward_dense that also returns the LAST layer's raw attention products of chosen rows: scores[r][h][j] =
  * q[score_rows[r]][h] . k[j][h] / sqrt(head_dim) for every row j of that row's utterance, fp32 [n_score][H][ld_scores]

@@ -564,7 +564,7 @@ class Oracle:
         rot = torch.cat((-x[..., h:], x[..., :h]), dim=-1)
         return x * cos + rot * sin
 
-    def stack(self, x, pos, lens, kv=None, layer_probe=None, causal=None, score_probe=None, final_norm=True):
+    def stack(self, x, pos, lens, kv=None, layer_probe=None, causal=None, score_probe=None, final_norm=True, kv_lens=None):
         """x: packed (sum(lens), d); pos: packed position ids; lens: rows per utterance.
         kv: optional list (per layer) of per-utterance [K, V] caches that are appended to
         (KV-cache mode); attention then runs each new row against cache + new rows.
@@ -599,6 +599,8 @@ class Oracle:
                 mask = torch.ones(n, Tk, dtype=torch.bool)
                 if causal is None or causal[b]:
                     mask = mask.tril(diagonal=past)
+                if kv_lens is not None:                                      # key-padding mask of a right-padded batch: the rows
+                    mask[:, kv_lens[b]:] = False                             # behind kv_lens[b] are queries, never keys
                 att = (qb @ kb.transpose(1, 2)) * scale
                 if score_probe is not None and l == self.L - 1:              # output_attentions: the raw scaled products of the
                     score_probe.append(att[:, -1, :].float().clone())        # newest row, (H, T) (arch/llama.py:429, :469-477)

@@ -171,7 +171,10 @@ class OracleV2(Oracle):
 
     # -- AR_NAR_V2.forward_len (ar_nar_v2.py:374-431; base_v2.py:652-678, :1296-1308) with len_use_logits ------------
     def len_v2(self, phns, proms, langs, frames_per_second=75):
-        w, out = self.w, []
+        """The head reads ``logit[..., -1, :]`` of the right-PADDED batch (base_v2.py:1298-1300): for an utterance shorter than
+        the longest that is a padding row -- zero embedding, position id 1 (base_v2.py:865-867; T_max - 1 under unified ids),
+        attending to the utterance's rows, never a key itself."""
+        w, xs, ps = self.w, [], []
         for i in range(len(phns)):
             segs = [w["phn_emb.weight"][phns[i].long()]]
             if langs is not None:
@@ -185,9 +188,21 @@ class OracleV2(Oracle):
             pos = torch.cat([torch.arange(e.shape[0] + (0 if j == len(segs) - 1 else 1), dtype=torch.int32) for j, e in enumerate(segs)])[: x.shape[0]]
             if self.unified_pos:
                 pos = torch.arange(x.shape[0], dtype=torch.int32)
-            causal = not self.cfg.experimental.noncausal_masks               # "len" is not among the causal levels (base_v2.py:1182)
-            hid = self.stack(x, pos, [x.shape[0]], causal=[causal], final_norm=not self.cfg.experimental.per_level_normalization)
-            lg = F.linear(hid[-1], w["len_decoder.head.weight"], w["len_decoder.head.bias"])
+            xs.append(x), ps.append(pos)
+        valid = [x.shape[0] for x in xs]
+        T = max(valid)
+        for i, n in enumerate(valid):
+            if n < T:
+                xs[i] = torch.cat((xs[i], torch.zeros((1, self.d), dtype=self.dtype)))
+                ps[i] = torch.cat((ps[i], torch.tensor([T - 1 if self.unified_pos else 1], dtype=torch.int32)))
+        lens = [x.shape[0] for x in xs]
+        causal = not self.cfg.experimental.noncausal_masks                   # "len" is not among the causal levels (base_v2.py:1182)
+        hid = self.stack(torch.cat(xs), torch.cat(ps), lens, causal=[causal] * len(lens), kv_lens=valid,
+                         final_norm=not self.cfg.experimental.per_level_normalization)
+        out, o = [], 0
+        for n in lens:
+            o += n
+            lg = F.linear(hid[o - 1], w["len_decoder.head.weight"], w["len_decoder.head.bias"])
             digits = lg.view(5, 10).argmax(dim=-1)
             out.append(int(int("".join(str(int(t)) for t in digits)) / frames_per_second * frames_per_second))
         return out

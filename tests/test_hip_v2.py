@@ -234,3 +234,21 @@ def test_v2_full_bf16_vs_oracle(gpu_device):
     ref = vo2.OracleV2(cfg, sd).ar_v2(phns, proms, langs, max_duration=3, temperature=0.0)
     for b in range(2):
         np.testing.assert_array_equal(out[b].cpu().numpy(), ref[b].numpy())
+
+
+def test_tiny_v2_len_vs_reference(gpu_device):
+    """Duration prediction with the 5-digit head (ar_nar_v2.py:374-431) == the reference's frames on a ragged batch -- where the
+    reference reads the shorter utterance's LAST PADDING ROW (base_v2.py:1298-1300 on the right-padded batch): reproduced by
+    one zero row that is a query and never a key (valle_forward_layers(kv_lens=)); alone, each utterance gives what the
+    restatement gives alone.  With the dataclass default head (one float) the reference's pass dies on a reshape: same here."""
+    z = load_golden("tiny_v2_len")
+    phns, proms, langs = golden_inputs(z)
+    m = hip_model("tiny_v2_len")
+    got = m(task_list=["len"] * 2, phns_list=phns, proms_list=proms, lang_list=langs)
+    assert got == [int(x) for x in z["frames"]]
+    o = oracle_v2("tiny_v2_len")
+    for i in range(2):
+        solo = m(task_list=["len"], phns_list=phns[i:i + 1], proms_list=proms[i:i + 1], lang_list=langs[i:i + 1])
+        assert solo == o.len_v2(phns[i:i + 1], proms[i:i + 1], langs[i:i + 1])
+    with pytest.raises(RuntimeError, match="is invalid for input of size 27"):
+        hip_model("tiny_v2")(task_list=["len"] * 2, phns_list=phns, proms_list=proms, lang_list=langs)

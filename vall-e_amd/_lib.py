@@ -116,7 +116,7 @@ SIGNATURES = {
     "valle_cfg_combine_cols": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_float, c_void_p]),
     "valle_forward_layers": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                      c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p,
-                                     c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                     c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "valle_decode_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "valle_ar_decode": (c_int, [c_void_p, C.POINTER(ARState), C.POINTER(SampleParams), c_int, c_void_p, c_int,
                                 c_void_p, c_size_t, c_void_p]),

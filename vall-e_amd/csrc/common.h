@@ -157,6 +157,8 @@ int valle_attn_row_scores_cache(const void* q, size_t q_row_stride, const void* 
 // attention launchers (ops_basic.hip)
 extern "C" int valle_attn_prefill_rowwise(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int M,
                                           int H, int Dh, int causal, int dtype, void* stream);
+int valle_attn_prefill_rowwise_kv(const void* qkv, void* out, const int32_t* cu_seqlens, const int32_t* kv_lens, int B, int M,
+                                  int H, int Dh, int causal, int dtype, void* stream);
 int valle_attn_decode_launch(const void* qkv, const void* kcache, const void* vcache, const int32_t* ctx_len,
                              const int32_t* cache_slot, void* out, int B, int H, int Dh, int cache_T,
                              int ctx_extra, int dtype, void* stream);

@@ -174,7 +174,7 @@ static int forward_dense_impl(valle_model* m, const int32_t* emb_idx, const int3
                               const int32_t* out_rows, int n_out, int head, float* logits, int ld_logits,
                               void* hidden_out, void* workspace, size_t workspace_bytes, void* stream,
                               const int32_t* score_rows, int n_score, float* scores, int ld_scores,
-                              const void* x_in = nullptr, int final_norm = 1) {
+                              const void* x_in = nullptr, int final_norm = 1, const int32_t* kv_lens = nullptr) {
     VALLE_REQUIRE(m && (emb_idx || x_in) && pos && cu_seqlens && workspace, VALLE_E_ARG, "valle_forward_dense: null pointer");
     VALLE_REQUIRE(B > 0 && M > 0, VALLE_E_ARG, "valle_forward_dense: empty batch (B=%d, M=%d)", B, M);
     VALLE_REQUIRE(n_out == 0 || out_rows, VALLE_E_ARG, "valle_forward_dense: out_rows missing");
@@ -206,7 +206,7 @@ static int forward_dense_impl(valle_model* m, const int32_t* emb_idx, const int3
         if (!fold) RUN(valle_rmsnorm(x, w.ln1, h, M, d, c.rms_eps, dt, s));
         void* kc = kcache ? (char*)kcache + (size_t)l * cache_layer_stride * es : nullptr;
         void* vc = vcache ? (char*)vcache + (size_t)l * cache_layer_stride * es : nullptr;
-        if (dt == VALLE_BF16 && !kcache && Dh == 64 && d % 64 == 0 && M >= 64) {
+        if (dt == VALLE_BF16 && !kcache && Dh == 64 && d % 64 == 0 && M >= 64) {   // (a zero padding row is fine: rinv = 1/sqrt(eps), times 0)
             // passes without a KV cache (NAR levels, NAR-len steps): RoPE rides in the projection's epilogue
             if (fold) RUN(valle_gemm_normed(x, w.f_qkv, qkv, M, 3 * d, d, 3 * d, VALLE_EPI_STORE, c.rms_eps, m->rope, pos, s));
             else RUN(valle_gemm_qkv_rope(h, w.w_qkv, m->rope, pos, qkv, M, d, d, s));
@@ -217,7 +217,8 @@ static int forward_dense_impl(valle_model* m, const int32_t* emb_idx, const int3
         }
         if (scores && l == c.n_layers - 1)      // output_attentions: the last layer's raw scaled products of the chosen rows
             RUN(valle_attn_row_scores_dense(qkv, d, score_rows, n_score, cu_seqlens, B, H, scores, ld_scores, dt, s));
-        RUN(valle_attn_prefill(qkv, h, cu_seqlens, B, M, max_T, H, Dh, causal, dt, s));
+        if (kv_lens) RUN(valle_attn_prefill_rowwise_kv(qkv, h, cu_seqlens, kv_lens, B, M, H, Dh, causal, dt, s));
+        else RUN(valle_attn_prefill(qkv, h, cu_seqlens, B, M, max_T, H, Dh, causal, dt, s));
         // Behind the last layer's attention only the rows the caller asked for are read again (the other rows' K/V have
         // been consumed): output projection and MLP of the last layer run on those rows alone -- the same arithmetic per
         // row, 1 row of ~311 per utterance in the prefill, the response rows (~60 %) in the NAR passes
@@ -284,12 +285,13 @@ extern "C" int valle_forward_dense_scores(valle_model* m, const int32_t* emb_idx
 extern "C" int valle_forward_layers(valle_model* m, const void* x_in, const int32_t* pos, const int32_t* cu_seqlens, int B,
                                     int M, int max_T, int causal, void* kcache, void* vcache, int cache_T,
                                     size_t cache_layer_stride, const int32_t* cache_slot, const int32_t* cache_pos0,
-                                    const int32_t* out_rows, int n_out, int final_norm, void* hidden_out, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+                                    const int32_t* out_rows, int n_out, int final_norm, const int32_t* kv_lens,
+                                    void* hidden_out, void* workspace, size_t workspace_bytes, void* stream) {
     VALLE_REQUIRE(x_in && hidden_out && n_out > 0, VALLE_E_ARG, "valle_forward_layers: x_in, hidden_out and out_rows are required");
+    VALLE_REQUIRE(!kv_lens || !kcache, VALLE_E_ARG, "valle_forward_layers: kv_lens (padding rows) and a KV cache do not go together");
     return forward_dense_impl(m, nullptr, pos, cu_seqlens, B, M, max_T, causal, kcache, vcache, cache_T, cache_layer_stride,
                               cache_slot, cache_pos0, out_rows, n_out, 0, nullptr, 0, hidden_out, workspace, workspace_bytes,
-                              stream, nullptr, 0, nullptr, 0, x_in, final_norm);
+                              stream, nullptr, 0, nullptr, 0, x_in, final_norm, kv_lens);
 }
 
 extern "C" size_t valle_decode_workspace_bytes(const valle_model* m, int B) {

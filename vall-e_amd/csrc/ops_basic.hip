@@ -243,6 +243,7 @@ __global__ __launch_bounds__(NW * 64) void attn_rowwise_kernel(AttnRowArgs a) {
         }
         const int start = a.cu[lo];
         n_keys = a.causal ? (row - start + 1) : (a.cu[lo + 1] - start);
+        if (a.ctx_len) n_keys = min(n_keys, a.ctx_len[lo]);                  // dense: optional key limit per item (padding rows behind it)
         kb = (const T*)a.k + (size_t)start * a.kv_row_stride + h * a.kv_head_stride;
         vb = (const T*)a.v + (size_t)start * a.kv_row_stride + h * a.kv_head_stride;
     }
@@ -332,6 +333,13 @@ __global__ __launch_bounds__(NW * 64) void attn_rowwise_kernel(AttnRowArgs a) {
 
 extern "C" int valle_attn_prefill_rowwise(const void* qkv, void* out, const int32_t* cu_seqlens, int B, int M,
                                           int H, int Dh, int causal, int dtype, void* stream) {
+    return valle_attn_prefill_rowwise_kv(qkv, out, cu_seqlens, nullptr, B, M, H, Dh, causal, dtype, stream);
+}
+
+// kv_lens (optional, per utterance, >= 1): a row reads at most the first kv_lens[b] rows of its utterance as keys -- the
+// reference's key-padding mask on a right-padded batch (rows behind kv_lens[b] are padding: queries, never keys)
+int valle_attn_prefill_rowwise_kv(const void* qkv, void* out, const int32_t* cu_seqlens, const int32_t* kv_lens, int B, int M,
+                                  int H, int Dh, int causal, int dtype, void* stream) {
     VALLE_REQUIRE(qkv && out && cu_seqlens, VALLE_E_ARG, "valle_attn_prefill: null pointer");
     VALLE_REQUIRE(Dh == 64, VALLE_E_UNSUPPORTED, "valle_attn_prefill: head_dim %d (only 64 is built)", Dh);
     if (M == 0) return VALLE_OK;
@@ -341,7 +349,7 @@ extern "C" int valle_attn_prefill_rowwise(const void* qkv, void* out, const int3
     a.q = qkv; a.q_row_stride = 3 * d;
     a.k = (const char*)qkv + (size_t)d * es; a.v = (const char*)qkv + (size_t)2 * d * es;
     a.kv_row_stride = 3 * d; a.kv_head_stride = Dh;
-    a.cu = cu_seqlens; a.out = out; a.out_row_stride = d; a.causal = causal; a.B = B;
+    a.cu = cu_seqlens; a.out = out; a.out_row_stride = d; a.causal = causal; a.B = B; a.ctx_len = kv_lens;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(M, H);
     if (dtype == VALLE_BF16) attn_rowwise_kernel<bf16, false, 4, 4><<<grid, 256, 0, s>>>(a);

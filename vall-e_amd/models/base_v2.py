@@ -206,10 +206,12 @@ class Base_V2(Base):
             out[i].append(("classifier_level", f"{'N' if timestep is not None else ''}AR:{q}:{q}"))
         return out
 
-    def plan(self, phns_list, lang_list, proms_list, resp_lens, tone_list=None, task="tts") -> PlanV2:
+    def plan(self, phns_list, lang_list, proms_list, resp_lens, tone_list=None, task="tts", pad_pos=None) -> PlanV2:
         """Layout phn | lang | prom | tone | resp (``len``: ... | len) with a ``sep`` row between segments
         (base_v2.py:622-678, :61-65, :797); position ids restart per segment, segments other than the task's output count
-        their trailing sep (base_v2.py:860-867).  resp_lens[i] = frames of utterance i's response (None: no resp segment)."""
+        their trailing sep (base_v2.py:860-867).  resp_lens[i] = frames of utterance i's response (None: no resp segment).
+        pad_pos[i] (optional; None = no row): position id of ONE zero-embedding padding row appended to utterance i -- the last
+        row of the reference's right-padded batch (forward_super, ``len`` task)."""
         off = self._off
         out_kind = "len" if task == "len" else "resp"
         B = len(resp_lens)
@@ -290,6 +292,9 @@ class Base_V2(Base):
                 pos = np.concatenate([pos, np.ones(idx.shape[0] - pos.shape[0], np.int32)])
             if self.unified_position_ids:
                 pos = np.arange(idx.shape[0], dtype=np.int32)
+            if pad_pos is not None and pad_pos[i] is not None:
+                idx = np.concatenate([idx, np.full((1, 8), -1, dtype=np.int32)])
+                pos = np.concatenate([pos, np.array([pad_pos[i]], dtype=np.int32)])
             if idx.shape[0] > self.max_position_embeddings:
                 raise ValueError(f"sequence of {idx.shape[0]} rows exceeds max_position_embeddings ({self.max_position_embeddings})")
             idx_all.append(idx), pos_all.append(pos), lens.append(idx.shape[0])
@@ -364,8 +369,9 @@ class Base_V2(Base):
             return 1
         return 0 if (timestep or task == "len") else 1
 
-    def forward_hidden(self, plan: PlanV2, x, dev, out_rows, causal=1):
-        """The llama stack on embeddings x -> the out_rows (device int32) of the last hidden state, (n_out, d)."""
+    def forward_hidden(self, plan: PlanV2, x, dev, out_rows, causal=1, kv_lens=None):
+        """The llama stack on embeddings x -> the out_rows (device int32) of the last hidden state, (n_out, d).
+        kv_lens (device int32, per utterance): rows behind kv_lens[b] are padding -- queries, never keys."""
         lib = L.load()
         n_out = int(out_rows.numel())
         hidden = torch.empty((n_out, self.d_model), dtype=self.dtype, device=self.device)
@@ -374,7 +380,7 @@ class Base_V2(Base):
         ws = self._workspace(lib.valle_dense_workspace_bytes(self._handle, plan.M, n_out))
         L.check(lib.valle_forward_layers(self._handle, L.ptr(x), L.ptr(dev[0]), L.ptr(dev[1]), plan.B, plan.M, plan.max_T, int(causal),
                                          None, None, 0, 0, None, None, L.ptr_any(out_rows), n_out,
-                                         0 if self.per_level_normalization else 1, L.ptr(hidden), L.ptr(ws), ws.numel(),
+                                         0 if self.per_level_normalization else 1, L.ptr(kv_lens), L.ptr(hidden), L.ptr(ws), ws.numel(),
                                          L.stream_ptr(self.device)))
         return hidden
 
@@ -485,13 +491,30 @@ class Base_V2(Base):
         col = lambda k: [get(it, k) for it in inputs] if any(get(it, k) is not None for it in inputs) else None
         resps = [get(it, "resp") for it in inputs]
         resp_lens = [None if r is None else int(r.shape[0]) for r in resps]
-        plan = self.plan(phn if any(p is not None for p in phn) else None, col("lang"), col("prom"), resp_lens, tone_list=col("tone"), task=task)
+        args = (phn if any(p is not None for p in phn) else None, col("lang"), col("prom"), resp_lens)
+        plan = self.plan(*args, tone_list=col("tone"), task=task)
+        kv_lens, valid_lens = None, list(plan.lens)
+        if task == "len" and len(set(plan.lens)) > 1:
+            # base_v2.py:1298-1300 reads ``logit[..., -1, :]`` of the right-PADDED batch: for an utterance shorter than the
+            # longest one that is a padding row -- a zero embedding at position 1 (the tail of the per-segment ids,
+            # base_v2.py:865-867; under unified ids HF's arange gives it T_max - 1) that attends to the utterance's rows and
+            # is no key itself.  One such row is appended and read, with the valid rows as the only keys.
+            T = plan.max_T
+            kv_lens = self._i32(np.array(plan.lens, dtype=np.int32))
+            plan = self.plan(*args, tone_list=col("tone"), task=task,
+                             pad_pos=[None if n == T else (T - 1 if self.unified_position_ids else 1) for n in plan.lens])
         codes = [_np(r) for r in resps if r is not None and r.shape[0] > 0]
         x, dev = self.build_x(plan, np.concatenate(codes) if codes else None)
         causal = self.is_causal(timestep, task)
         if task == "len":
+            if not self.len_use_logits:
+                # the reference reshapes every ``len`` utterance's head output to (-1, 5, 10) first (base_v2.py:1279-1283): with
+                # the single-float head that is a (T, 1) tensor, and the call dies unless T is a multiple of 50
+                for n in valid_lens:
+                    if n % 50:
+                        raise RuntimeError(f"shape '[-1, 5, 10]' is invalid for input of size {n}")
             rows = self._i32(plan.cu[1:] - 1)
-            hidden = self.forward_hidden(plan, x, dev, rows, causal)
+            hidden = self.forward_hidden(plan, x, dev, rows, causal, kv_lens=kv_lens)
             lg = self.aux_decode("len_decoder", hidden)                                # last row of every utterance (:1298-1300)
             if not self.len_use_logits:
                 return Logits([float(v) for v in lg[:, 0].cpu()], None, inputs, None, None, None)
