@@ -131,7 +131,8 @@ class OracleV2(Oracle):
         whatever torch.topk returns (the reference's behaviour on this torch build: an internal of its partial sort);
         "lowest_index": the lower index first (a stable sort), the rule valle_mask_lowest implements."""
         kw = convert_kwargs(dict(kw), "ar_")
-        lens = [clamp(int(l), kw.pop("min_duration", 1), kw.pop("max_duration", 500)) for l in lens]
+        lo, hi = kw.pop("min_duration", 1), kw.pop("max_duration", 500)
+        lens = [clamp(int(l), lo, hi) for l in lens]
         max_steps = kw.get("max_steps", 25)
         annealed = kw.get("annealed_sampling", True)
         temperature = kw.pop("temperature", 0.0)

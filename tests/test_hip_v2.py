@@ -252,3 +252,23 @@ def test_tiny_v2_len_vs_reference(gpu_device):
         assert solo == o.len_v2(phns[i:i + 1], proms[i:i + 1], langs[i:i + 1])
     with pytest.raises(RuntimeError, match="is invalid for input of size 27"):
         hip_model("tiny_v2")(task_list=["len"] * 2, phns_list=phns, proms_list=proms, lang_list=langs)
+
+
+def test_v2_tts_batched_inference_narlen(gpu_device):
+    """TTS.batched_inference(modality="nar-len") on a version-7 model (inference.py:326-336: the duration head, then the
+    demasking of all levels) == the restatement fed the same calls; the "ar+nar" modality's second call hands (frames, 8)
+    codes back to the model, which the reference takes for a training batch (ar_nar_v2.py:625-629): refused by name."""
+    from vall_e_amd.inference import TTS
+    z = load_golden("tiny_v2_len")
+    phns, proms, langs = golden_inputs(z)
+    tts = TTS(config=model_cfg("tiny_v2_len"), device="cuda:0", dtype=torch.float32, state_dict=synth_weights("tiny_v2_len"))
+    kw = dict(max_steps=3, top_no=0.0, max_duration=14, temperature=0.0)
+    out = tts.batched_inference(phns, references=proms, languages=langs, modality="nar-len", seed=5, **kw)
+    o = oracle_v2("tiny_v2_len")
+    lens = [int(l * 1.05) for l in o.len_v2(phns, proms, langs)]
+    ref = o.nar_masked_v2(phns, proms, langs, lens, tie_rule="lowest_index", **kw)
+    for b in range(2):
+        assert out[b].shape == (14, 8)
+        np.testing.assert_array_equal(out[b].cpu().numpy(), ref[b].numpy())
+    with pytest.raises(NotImplementedError, match="training"):
+        tts.batched_inference(phns, references=proms, languages=langs, modality="ar+nar", max_duration=3, temperature=0.0)
