@@ -387,6 +387,15 @@ typedef struct {
                                  * cache_T or read past the RoPE table -- the kernels do not check        */
 } valle_ar_state;
 
+/* One KV-cache decode step of the stack for embeddings computed outside (the version >= 7 AR loop, models/ar_nar_v2.py:504-572;
+ * the reference recomputes the whole sequence per step, use_cache=False at models/base_v2.py:539): x_in [B][d] in dtype = the
+ * AudioEncoder's row of every utterance's newest frame, pos_in [B] its position id.  Of the state, B / ctx_len / cache_slot /
+ * kcache / vcache / cache_T / cache_layer_stride / max_ctx are read; the row's key and value are appended and ctx_len[b] is
+ * incremented.  hidden_out [B][d]: the last hidden state, through the final RMSNorm when final_norm != 0. */
+int valle_ar_decode_layers(valle_model* m, const valle_ar_state* st, const void* x_in, const int32_t* pos_in, void* hidden_out,
+                           int final_norm, void* workspace, size_t workspace_bytes, void* stream);
+
+
 size_t valle_decode_workspace_bytes(const valle_model* m, int B);
 
 /* n_steps AR decode steps, enqueued back to back on `stream` with no host synchronisation:

@@ -127,15 +127,42 @@ def test_tiny_v2_forward_vs_reference(gpu_device):
 
 
 def test_tiny_v2_ar_vs_reference(gpu_device):
-    """Greedy AR of 8 codes per step == the reference's codes (golden tiny_v2_ar), whatever the step chunking."""
+    """Greedy AR of 8 codes per step == the reference's codes (golden tiny_v2_ar), on the KV cache and on the reference's own
+    schedule (the whole sequence per step), whatever the step chunking; the logits of every step agree between the two
+    schedules far inside the golden's smallest top-2 margin."""
     z = load_golden("tiny_v2_ar")
     phns, proms, langs = golden_inputs(z)
     m = hip_model("tiny_v2")
-    for chunk in (16, 1, 4):
-        out = m(task_list=["tts"] * 2, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=int(z["steps"]), temperature=0.0,
-                step_chunk=chunk)
-        for b in range(2):
-            np.testing.assert_array_equal(out[b].cpu().numpy(), z[f"ar_codes_{b}"])
+    kept = {}
+    for cache in (True, False):
+        for chunk in (16, 1, 4):
+            lg = []
+            out = m(task_list=["tts"] * 2, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=int(z["steps"]), temperature=0.0,
+                    step_chunk=chunk, kv_cache=cache, return_logits=lg)
+            for b in range(2):
+                np.testing.assert_array_equal(out[b].cpu().numpy(), z[f"ar_codes_{b}"])
+            kept[cache] = torch.stack(lg)
+    err = (kept[True] - kept[False]).abs().max().item()
+    assert err * 10 < float(z["min_top2_gap"]), (err, float(z["min_top2_gap"]))
+
+
+def test_v2_ar_unified_positions_cache_equals_recompute(gpu_device):
+    """unified_position_ids (the dataclass default): the cached step's position is rows-in-front + frame; 10 greedy steps on a
+    ragged batch of 3 give the same codes on the cache as on the whole-sequence schedule."""
+    import model_configs as vcfg
+    from vall_e_amd.models import get_model
+    from vall_e_amd.weights import synth_state_dict
+    from vall_e_amd.synth import synth_batch
+    cfg = vcfg.tiny_v2_model()
+    cfg.experimental.unified_position_ids = True
+    m = get_model(cfg, training=False)
+    m.load_state_dict(synth_state_dict(cfg, 1234))
+    m.to("cuda:0", torch.float32)
+    phns, proms, langs = synth_batch(5, 3, n_phn=12, n_prom=20, ragged=True)
+    a = m(task_list=["tts"] * 3, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=10, temperature=0.0, kv_cache=True)
+    b = m(task_list=["tts"] * 3, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=10, temperature=0.0, kv_cache=False, step_chunk=3)
+    for x, y in zip(a, b):
+        assert x.shape == (10, 8) and torch.equal(x, y)
 
 
 @pytest.mark.parametrize("name,kind", [("tiny_v2_narlen_noties", "tiny_v2"), ("tiny_v2_nc_narlen_noties", "tiny_v2_nc"),
@@ -229,11 +256,17 @@ def test_v2_full_bf16_vs_oracle(gpu_device):
     for i in range(2):
         n = resps[i].shape[0]
         assert rel_l2(got[i][:, -n:], want[i][:, -n:].float()) < 4e-2
+    # bf16 AR on the fused decode kernels (KV cache) against the whole-sequence schedule: the logits of 4 steps within the bf16 bar
+    la, lb = [], []
+    m(task_list=["tts"] * 2, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=4, temperature=0.0, kv_cache=True, return_logits=la)
+    m(task_list=["tts"] * 2, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=4, temperature=0.0, kv_cache=False, return_logits=lb)
+    assert rel_l2(la[0], lb[0]) < 4e-2
     m.to("cuda:0", torch.float32)
-    out = m(task_list=["tts"] * 2, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=3, temperature=0.0)
     ref = vo2.OracleV2(cfg, sd).ar_v2(phns, proms, langs, max_duration=3, temperature=0.0)
-    for b in range(2):
-        np.testing.assert_array_equal(out[b].cpu().numpy(), ref[b].numpy())
+    for cache in (True, False):
+        out = m(task_list=["tts"] * 2, phns_list=phns, proms_list=proms, lang_list=langs, max_duration=3, temperature=0.0, kv_cache=cache)
+        for b in range(2):
+            np.testing.assert_array_equal(out[b].cpu().numpy(), ref[b].numpy())
 
 
 def test_tiny_v2_len_vs_reference(gpu_device):

@@ -117,6 +117,7 @@ SIGNATURES = {
     "valle_forward_layers": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                      c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p,
                                      c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "valle_ar_decode_layers": (c_int, [c_void_p, C.POINTER(ARState), c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "valle_decode_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "valle_ar_decode": (c_int, [c_void_p, C.POINTER(ARState), C.POINTER(SampleParams), c_int, c_void_p, c_int,
                                 c_void_p, c_size_t, c_void_p]),

@@ -147,6 +147,43 @@ __global__ __launch_bounds__(128) void dec_prepare_frag_kernel(const bf16* __res
         *reinterpret_cast<bf16x8*>(xf + (size_t)(b >> 4) * 16 * d + dec_frag_off<1>(b & 15, c, d)) = *reinterpret_cast<const bf16x8*>(src + c);
 }
 
+// decode step on embeddings computed outside (version >= 7: the AudioEncoder's row of the newest frame): x_in [B][d] row-major,
+// pos_in [B] -> the same outputs as the two kernels above
+template <typename T>
+__global__ __launch_bounds__(128) void dec_prepare_x_kernel(const T* __restrict__ x_in, const int32_t* __restrict__ pos_in,
+                                                            T* __restrict__ x, bf16* __restrict__ xf, int32_t* __restrict__ pos,
+                                                            int32_t* __restrict__ cu, int d, int B,
+                                                            const float* __restrict__ rope_tab, float* __restrict__ rope_m) {
+    constexpr int VEC = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    const int b = blockIdx.x;
+    const int p = pos_in[b];
+    if (threadIdx.x == 0) {
+        pos[b] = p;
+        if (cu) { cu[b] = b; if (b == B - 1) cu[B] = B; }
+    }
+    if (rope_m && threadIdx.x < 64) rope_m[b * 64 + threadIdx.x] = rope_tab[(size_t)p * 64 + threadIdx.x];
+    for (int c = threadIdx.x * VEC; c < d; c += 128 * VEC) {
+        const vec_t v = *reinterpret_cast<const vec_t*>(x_in + (size_t)b * d + c);
+        if constexpr (sizeof(T) == 2) {
+            if (xf) { *reinterpret_cast<bf16x8*>(xf + (size_t)(b >> 4) * 16 * d + dec_frag_off<1>(b & 15, c, d)) = v; continue; }
+        }
+        *reinterpret_cast<vec_t*>(x + (size_t)b * d + c) = v;
+    }
+}
+
+// fragment-order x of the wave-streaming path -> row-major rows
+__global__ __launch_bounds__(128) void dec_unfrag_kernel(const bf16* __restrict__ xf, bf16* __restrict__ out, int d) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x * 8; c < d; c += 128 * 8)
+        *reinterpret_cast<bf16x8*>(out + (size_t)b * d + c) = *reinterpret_cast<const bf16x8*>(xf + (size_t)(b >> 4) * 16 * d + dec_frag_off<1>(b & 15, c, d));
+}
+
+__global__ void dec_bump_ctx_kernel(int32_t* __restrict__ ctx_len, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) ctx_len[b] += 1;
+}
+
 struct Carver {
     char* p; size_t left; bool ok;
     Carver(void* base, size_t n) : p((char*)base), left(n), ok(true) {}
@@ -310,11 +347,13 @@ extern "C" size_t valle_decode_workspace_bytes(const valle_model* m, int B) {
 static int ar_decode_impl(valle_model* m, const valle_ar_state* st, const valle_sample_params* sp,
                           int n_steps, float* logits_out, int ld_logits,
                           void* workspace, size_t workspace_bytes, void* stream,
-                          float* scores = nullptr, int ld_scores = 0) {
+                          float* scores = nullptr, int ld_scores = 0,
+                          const void* x_in = nullptr, const int32_t* pos_in = nullptr, void* hidden_out = nullptr, int final_norm = 1) {
     VALLE_REQUIRE(m && st && workspace, VALLE_E_ARG, "valle_ar_decode: null pointer");
+    const bool outside = x_in != nullptr;          // embeddings in, hidden state out: no token sequence, no head, no sampler
     VALLE_REQUIRE(sp != nullptr || n_steps == 1, VALLE_E_ARG, "valle_ar_decode: without sampler params only one step can run");
     VALLE_REQUIRE(n_steps >= 1, VALLE_E_ARG, "valle_ar_decode: n_steps %d", n_steps);
-    VALLE_REQUIRE(st->B > 0 && st->seq && st->seq_len && st->ctx_len && st->stopped && st->kcache && st->vcache && st->cache_slot,
+    VALLE_REQUIRE(st->B > 0 && st->ctx_len && st->kcache && st->vcache && st->cache_slot && (outside || (st->seq && st->seq_len && st->stopped)),
                   VALLE_E_ARG, "valle_ar_decode: incomplete state");
     // every step appends one key per utterance at ctx_len[b] and reads the RoPE row of its position (<= ctx_len[b]):
     // the host's bound on the contexts keeps both inside the cache and the table
@@ -323,7 +362,7 @@ static int ar_decode_impl(valle_model* m, const valle_ar_state* st, const valle_
                   "valle_ar_decode: %d cached positions + %d steps exceed cache_T %d", st->max_ctx, n_steps, st->cache_T);
     VALLE_REQUIRE((long)st->max_ctx + n_steps <= m->cfg.max_pos, VALLE_E_ARG,
                   "valle_ar_decode: %d cached positions + %d steps exceed the RoPE table (%d rows)", st->max_ctx, n_steps, m->cfg.max_pos);
-    VALLE_REQUIRE(st->head >= 0 && st->head < m->n_cls && st->vocab == m->head_n[st->head] && st->vocab <= 2048,
+    VALLE_REQUIRE(outside || (st->head >= 0 && st->head < m->n_cls && st->vocab == m->head_n[st->head] && st->vocab <= 2048),
                   VALLE_E_ARG, "valle_ar_decode: bad head/vocab");
     VALLE_REQUIRE(logits_out == nullptr || ld_logits >= st->vocab, VALLE_E_ARG, "valle_ar_decode: ld_logits too small");
     const valle_config& c = m->cfg;
@@ -347,14 +386,19 @@ static int ar_decode_impl(valle_model* m, const valle_ar_state* st, const valle_
                   valle_decode_workspace_bytes(m, B));
     hipStream_t s = (hipStream_t)stream;
     const bool wavepath = (dt == VALLE_BF16) && B <= 32 && (d == 256 || d == 512 || d == 768 || d == 1024) && f == 4 * d &&
-                          m->layers[0].pn_qkv && m->layers[0].p_o && m->layers[0].pn_gu && m->layers[0].p_down && m->head_pn[st->head];
+                          m->layers[0].pn_qkv && m->layers[0].p_o && m->layers[0].pn_gu && m->layers[0].p_down && (outside || m->head_pn[st->head]);
     // early exit of finished utterances: only with the fused sampler (it freezes their seq_len / ctx_len) on the fused path
     const bool early = st->early_exit != 0 && sp != nullptr && wavepath;
     int rc;
     for (int step = 0; step < n_steps; ++step) {
         float* lg = logits_out ? logits_out + (size_t)step * B * ld_logits : lg_ws;
         const int ldl = logits_out ? ld_logits : 2048;
-        if (wavepath && step > 0) {
+        if (outside) {
+            if (dt == VALLE_BF16)
+                dec_prepare_x_kernel<bf16><<<B, 128, 0, s>>>((const bf16*)x_in, pos_in, (bf16*)x, wavepath ? xf : nullptr, pos, cu, d, B, m->rope, wavepath ? rope_m : nullptr);
+            else
+                dec_prepare_x_kernel<float><<<B, 128, 0, s>>>((const float*)x_in, pos_in, (float*)x, nullptr, pos, cu, d, B, m->rope, nullptr);
+        } else if (wavepath && step > 0) {
             // the previous step's sampler already embedded its token (SampleArgs.nx_*)
         } else if (wavepath)
             dec_prepare_frag_kernel<<<B, 128, 0, s>>>((const bf16*)m->emb, st->resp_emb_row0, st->seq, st->max_steps, st->seq_len, st->resp_pos0, xf, pos, d, m->rope, rope_m);
@@ -400,6 +444,16 @@ static int ar_decode_impl(valle_model* m, const valle_ar_state* st, const valle_
                 RUN(valle_gemm(ff, w.w_down, nullptr, x, x, B, d, f, d, VALLE_EPI_RESID, dt, s));
             }
         }
+        if (outside) {
+            // the newest row of the last hidden state, raw or through the final norm; the caller's decoder and sampler follow
+            void* raw = final_norm ? h : hidden_out;
+            if (wavepath) dec_unfrag_kernel<<<B, 128, 0, s>>>(xf, (bf16*)raw, d);
+            else VALLE_HIP_CHECK(hipMemcpyAsync(raw, x, (size_t)B * d * es, hipMemcpyDeviceToDevice, s));
+            if (final_norm) RUN(valle_rmsnorm(h, m->final_norm, hidden_out, B, d, c.rms_eps, dt, s));
+            dec_bump_ctx_kernel<<<ceil_div(B, 64), 64, 0, s>>>(st->ctx_len, B);       // the row's key / value now sit in the cache
+            VALLE_LAUNCH_CHECK();
+            break;
+        }
         if (wavepath) {
             DecWArgs hd{};
             hd.x = xf; hd.W = (const bf16*)m->head_pn[st->head]; hd.bias = m->head_b[st->head]; hd.out = lg; hd.ldo = ldl;
@@ -437,6 +491,14 @@ extern "C" int valle_ar_decode_scores(valle_model* m, const valle_ar_state* st, 
     VALLE_REQUIRE(st && ld_scores >= st->max_ctx + 1, VALLE_E_ARG, "valle_ar_decode_scores: ld_scores too small for max_ctx + 1 keys");
     VALLE_REQUIRE(m && m->cfg.d_model / m->cfg.n_heads == 64, VALLE_E_UNSUPPORTED, "valle_ar_decode_scores: head_dim 64 only");
     return ar_decode_impl(m, st, nullptr, 1, logits_out, ld_logits, workspace, workspace_bytes, stream, scores, ld_scores);
+}
+
+// One decode step of the stack on embeddings computed outside (version >= 7 AR loop: the AudioEncoder's row of the newest frame
+// in, the last hidden state out, models/ar_nar_v2.py:504-572 with the KV cache the reference leaves unused, base_v2.py:539).
+extern "C" int valle_ar_decode_layers(valle_model* m, const valle_ar_state* st, const void* x_in, const int32_t* pos_in,
+                                      void* hidden_out, int final_norm, void* workspace, size_t workspace_bytes, void* stream) {
+    VALLE_REQUIRE(x_in && pos_in && hidden_out, VALLE_E_ARG, "valle_ar_decode_layers: x_in, pos_in and hidden_out are required");
+    return ar_decode_impl(m, st, nullptr, 1, nullptr, 0, workspace, workspace_bytes, stream, nullptr, 0, x_in, pos_in, hidden_out, final_norm);
 }
 
 // ------------------------------------------------------------------ guided AR steps without a host round trip

@@ -7,6 +7,7 @@ whole loop; the sequence layout is planned and uploaded once per call.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 
 import numpy as np
@@ -134,11 +135,15 @@ class AR_NAR_V2(Base_V2):
     # ------------------------------------------------------------------------------------ AR
     def forward_ar(self, task_list=None, phns_list=None, proms_list=None, resps_list=None, lang_list=None, tone_list=None,
                    len_list=None, text_list=None, disable_tqdm=False, use_lora=None, **sampling_kwargs):
-        """Autoregression over frames, all levels of a frame per step (ar_nar_v2.py:433-589).  As in the reference every
-        step runs the whole sequence through the stack (its state is never used: ``use_cache=False``, base_v2.py:539); the
-        encoder output of a frame is computed once and kept.  Steps are enqueued in chunks without a host round trip; the
-        stop test reads the codes of a chunk back in one copy."""
+        """Autoregression over frames, all levels of a frame per step (ar_nar_v2.py:433-589).  The reference runs the whole
+        sequence through the stack every step (its state is never used: ``use_cache=False``, base_v2.py:539); here the prompt
+        is prefilled once into a KV cache and every step runs the newest frame's encoder row through one decode step of the
+        stack (``valle_ar_decode_layers``), the AudioDecoder and the sampler -- the same function of the same inputs, as the
+        version-5 loop does it.  ``kv_cache=False`` keeps the reference's schedule (whole sequence per step, the encoder
+        output of a frame computed once).  Steps are enqueued in chunks without a host round trip; the stop test reads the
+        codes of a chunk back in one copy."""
         self._prepare()
+        lib = L.load()
         if text_list is not None and phns_list is None:
             phns_list = [None if t is None else RawText(t) for t in text_list]
         kw = convert_kwargs(dict(sampling_kwargs), "ar_")
@@ -155,34 +160,68 @@ class AR_NAR_V2(Base_V2):
         step_chunk = int(kw.get("step_chunk", 16))
         want_logits = kw.get("return_logits")                                      # tests: list receiving (B, L, V) per step
         seed = kw.get("seed", 0)
+        use_cache = bool(kw.get("kv_cache", True))
         B, Lv, d, dev = len(phns_list), self.n_resp_levels, self.d_model, self.device
         n_steps = max_duration // max(1, self.causal_size)
         if n_steps <= 0:
             return [torch.zeros((0, Lv), dtype=torch.int64, device=dev) for _ in range(B)]
-        stream = L.stream_ptr(dev)
         # codes of step t: [t][level][utterance] (the sampler's row order), summed encoder rows of step t: [t][utterance][d]
         step_codes = torch.empty((n_steps, Lv, B), dtype=torch.int32, device=dev)
         enc = torch.empty((n_steps, B, d), dtype=self.dtype, device=dev)
         host_codes = np.zeros((0, Lv, B), dtype=np.int64)
         n, done = 0, False
         spk = {k: v for k, v in kw.items() if k in ("top_k", "top_p", "min_p", "top_no")}
+
+        def sample_and_encode(t, logits):                                          # logits (L, B, ld): row l * B + b
+            if want_logits is not None:
+                want_logits.append(logits[:, :, :self.audio_vocab].transpose(0, 1).clone())
+            sp = self.sample_params_v2(temperature=temperature, seed=seed, offset=4000 + t, **spk)
+            self.sample_flat(logits.view(Lv * B, -1), Lv * B, sp, ids_out=step_codes[t].view(-1))
+            y = self.encode_frames("resps_emb", step_codes[t], B, B)
+            self.place_frames("resps_emb", y, B, None, enc[t])
+
+        if use_cache:
+            H, Dh, Lyr = self.n_heads, d // self.n_heads, self.n_layers
+            plan = self.plan(phns_list, lang_list, proms_list, [0] * B, tone_list=tone_list)
+            if plan.max_T + n_steps + 1 > self.max_position_embeddings:
+                raise ValueError(f"sequence of {plan.max_T} + {n_steps} steps exceeds max_position_embeddings ({self.max_position_embeddings})")
+            cache_T = -(-(plan.max_T + n_steps + 1) // 8) * 8
+            stride = B * H * cache_T * Dh
+            kc = torch.empty((Lyr, B, H, cache_T, Dh), dtype=self.dtype, device=dev)
+            vc = torch.empty_like(kc)
+            slot, pos0 = self._i32(np.arange(B)), self._filled(B, torch.int32)
+            x, pdev = self.build_x(plan)
+            last = self._i32(plan.cu[1:] - 1)
+            hidden = self.forward_hidden(plan, x, pdev, last, 1, cache=(kc, vc, cache_T, stride, slot, pos0))
+            ctx_len = self._i32(plan.lens)
+            # position id of response frame t: t under per-segment ids, rows in front of the response + t under unified ids
+            base_pos = np.array(plan.lens if self.unified_position_ids else [0] * B, dtype=np.int32)
+            st = L.ARState(B, n_steps, None, None, ctx_len.data_ptr(), None, slot.data_ptr(), None, None, kc.data_ptr(), vc.data_ptr(),
+                           cache_T, stride, 0, 0, 0, 0, int(plan.max_T))
+            ws_bytes = lib.valle_decode_workspace_bytes(self._handle, B)
+            ws = self._workspace(max(ws_bytes, 1))
+            fin = 0 if self.per_level_normalization else 1
         while n < n_steps and not done:
             chunk = min(step_chunk, n_steps - n)
+            if use_cache:
+                pos_chunk = self._i32(np.stack([base_pos + t - 1 for t in range(max(n, 1), n + chunk)]) if n + chunk > max(n, 1) else np.zeros((0, B), np.int32))
             for t in range(n, n + chunk):
-                plan = self.plan(phns_list, lang_list, proms_list, [t] * B, tone_list=tone_list)
-                x, pdev = self.build_x(plan)                                       # resp_dst: utterance-major (b, frame)
+                if use_cache:
+                    if t > 0:                                                      # frame t - 1 enters the stack, its hidden row predicts frame t
+                        st.max_ctx = int(plan.max_T) + t - 1
+                        hidden = torch.empty((B, d), dtype=self.dtype, device=dev)
+                        L.check(lib.valle_ar_decode_layers(self._handle, C.byref(st), L.ptr(enc[t - 1]), L.ptr(pos_chunk[t - max(n, 1)]), L.ptr(hidden),
+                                                           fin, L.ptr(ws), ws.numel(), L.stream_ptr(dev)))
+                    sample_and_encode(t, self.decode(hidden))
+                    continue
+                plan_t = self.plan(phns_list, lang_list, proms_list, [t] * B, tone_list=tone_list)
+                x, pdev = self.build_x(plan_t)                                     # resp_dst: utterance-major (b, frame)
                 if t > 0:
                     # frame-major kept rows [t'][b] -> the packed rows of (b, t')
-                    dst = self._i32(plan.resp_dst.reshape(B, t).T.reshape(-1))
+                    dst = self._i32(plan_t.resp_dst.reshape(B, t).T.reshape(-1))
                     self.copy_rows(enc, t * B, dst, x)
-                last = self._i32(plan.cu[1:] - 1)
-                logits = self.decode(self.forward_hidden(plan, x, pdev, last, 1))   # (L, B, ld): row l * B + b
-                if want_logits is not None:
-                    want_logits.append(logits[:, :, :self.audio_vocab].transpose(0, 1).clone())
-                sp = self.sample_params_v2(temperature=temperature, seed=seed, offset=4000 + t, **spk)
-                self.sample_flat(logits.view(Lv * B, -1), Lv * B, sp, ids_out=step_codes[t].view(-1))
-                y = self.encode_frames("resps_emb", step_codes[t], B, B)
-                self.place_frames("resps_emb", y, B, None, enc[t])
+                last = self._i32(plan_t.cu[1:] - 1)
+                sample_and_encode(t, self.decode(self.forward_hidden(plan_t, x, pdev, last, 1)))   # (L, B, ld): row l * B + b
             got = step_codes[n:n + chunk].cpu().numpy().astype(np.int64)
             host_codes = np.concatenate([host_codes, got])
             n += chunk

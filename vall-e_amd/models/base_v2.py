@@ -369,17 +369,19 @@ class Base_V2(Base):
             return 1
         return 0 if (timestep or task == "len") else 1
 
-    def forward_hidden(self, plan: PlanV2, x, dev, out_rows, causal=1, kv_lens=None):
+    def forward_hidden(self, plan: PlanV2, x, dev, out_rows, causal=1, kv_lens=None, cache=None):
         """The llama stack on embeddings x -> the out_rows (device int32) of the last hidden state, (n_out, d).
-        kv_lens (device int32, per utterance): rows behind kv_lens[b] are padding -- queries, never keys."""
+        kv_lens (device int32, per utterance): rows behind kv_lens[b] are padding -- queries, never keys.
+        cache = (k, v, cache_T, layer_stride, slot, pos0): every row's rotated key and its value are also written there."""
         lib = L.load()
         n_out = int(out_rows.numel())
         hidden = torch.empty((n_out, self.d_model), dtype=self.dtype, device=self.device)
         if n_out == 0:
             return hidden
         ws = self._workspace(lib.valle_dense_workspace_bytes(self._handle, plan.M, n_out))
+        kc, vc, cache_T, stride, slot, pos0 = cache if cache is not None else (None, None, 0, 0, None, None)
         L.check(lib.valle_forward_layers(self._handle, L.ptr(x), L.ptr(dev[0]), L.ptr(dev[1]), plan.B, plan.M, plan.max_T, int(causal),
-                                         None, None, 0, 0, None, None, L.ptr_any(out_rows), n_out,
+                                         L.ptr(kc), L.ptr(vc), cache_T, stride, L.ptr(slot), L.ptr(pos0), L.ptr_any(out_rows), n_out,
                                          0 if self.per_level_normalization else 1, L.ptr(kv_lens), L.ptr(hidden), L.ptr(ws), ws.numel(),
                                          L.stream_ptr(self.device)))
         return hidden
