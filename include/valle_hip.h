@@ -305,6 +305,14 @@ int valle_forward_dense(valle_model* m, const int32_t* emb_idx, const int32_t* p
 
 /* ---------------------------------------------------- version >= 7 model ("v2": models/base_v2.py) ---- */
 
+/* valle_gemm for FEW rows in bf16 (a decode step's encoder / decoder linears: 16 .. a few hundred rows): one workgroup per
+ * 16 output columns, K split over its waves, row-major weights streamed as they lie.  Same arguments and epilogues as
+ * valle_gemm (STORE, RESID, F32OUT, GELU, RESID_BIAS; not GEGLU); K must be a multiple of 128.  An output's K sum is the
+ * sum of four partial sums, so the last bits can differ from valle_gemm's. */
+int valle_gemm_skinny(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int ldc,
+                      int epilogue, int dtype, void* stream);
+
+
 /* nn.LayerNorm over the last dimension (with weight and bias, eps inside the square root): the AudioDecoder's per-level
  * norm (models/base_v2.py:184).  x, w, b, out in dtype. */
 int valle_layernorm(const void* x, const void* w, const void* b, void* out, int rows, int d, float eps, int dtype, void* stream);

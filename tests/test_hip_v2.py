@@ -305,3 +305,32 @@ def test_v2_tts_batched_inference_narlen(gpu_device):
         np.testing.assert_array_equal(out[b].cpu().numpy(), ref[b].numpy())
     with pytest.raises(NotImplementedError, match="training"):
         tts.batched_inference(phns, references=proms, languages=langs, modality="ar+nar", max_duration=3, temperature=0.0)
+
+
+@pytest.mark.parametrize("shape", [(16, 2048, 1024), (16, 1025, 1024), (128, 1024, 2048), (5, 48, 128), (200, 512, 256), (33, 1000, 640)])
+def test_gemm_skinny(gpu_device, shape):
+    """The few-rows GEMM (valle_gemm_skinny) against fp64, every epilogue it builds, ragged M and N."""
+    from vall_e_amd import _lib as L
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).bfloat16()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    bias = (0.3 * torch.randn(N, generator=g))
+    resid = torch.randn(M, N, generator=g).bfloat16()
+    acc = A.double() @ W.double().T
+    Ad, Wd, Rd = A.to(gpu_device), W.to(gpu_device), resid.to(gpu_device)
+    b16, b32 = bias.bfloat16().to(gpu_device), bias.to(gpu_device)
+    accb = acc + bias.bfloat16().double()
+    cases = ((L.EPI_STORE, accb, b16, torch.bfloat16), (L.EPI_GELU, torch.nn.functional.gelu(accb), b16, torch.bfloat16),
+             (L.EPI_RESID_BIAS, resid.double() + accb, b16, torch.bfloat16), (L.EPI_RESID, resid.double() + acc, None, torch.bfloat16),
+             (L.EPI_F32OUT, acc + bias.double(), b32, torch.float32))
+    ldc = (N + 7) // 8 * 8
+    for epi, want, bd, odt in cases:
+        Cd = torch.zeros((M, ldc), dtype=odt, device=gpu_device)
+        Rp = None
+        if epi in (L.EPI_RESID, L.EPI_RESID_BIAS):
+            Rp = torch.zeros((M, ldc), dtype=torch.bfloat16, device=gpu_device)
+            Rp[:, :N] = Rd
+        L.check(L.load().valle_gemm_skinny(L.ptr(Ad), L.ptr(Wd), L.ptr(bd), L.ptr(Rp), L.ptr(Cd), M, N, K, ldc, epi, L.BF16, L.stream_ptr()))
+        assert rel_l2(Cd[:, :N], want) < (2e-2 if odt == torch.bfloat16 else 2e-5), (epi, shape)
+        assert float(Cd[:, N:].abs().max() if ldc > N else 0) == 0.0          # nothing written past N

@@ -675,6 +675,101 @@ extern "C" int valle_gemm_normed(const void* A, const void* Wf, void* C, int M, 
     return VALLE_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Few rows, bf16 (M up to a few hundred): the 128 x 128 tile kernels leave most of the chip idle there (N = 2,048 is 16
+// workgroups).  One workgroup per 16 output columns instead; its four waves split K, every wave streams its share of the 16
+// weight rows straight from the row-major matrix -- a lane's 16 bytes ARE its MFMA A fragment (row fr, k = fq * 8 ..) -- and
+// of the activation rows likewise (B fragment), the four partial sums meet in LDS.  Weights are read once per 16 rows of M
+// (from L2 behind the first tile).  Used where the caller asks for it (valle_gemm_skinny): the version >= 7 encoder /
+// decoder linears of a decode step.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_skinny_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W,
+                                                               const void* __restrict__ bias, const bf16* resid, void* Cout,
+                                                               int M, int N, int K, int ldc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int nrow = min(n0 + fr, N - 1);                       // clamped: rows past N are computed and never stored
+    const int kw = K >> 2, kbase = wave * kw;                    // K % 128 == 0 (host check): a wave's share is whole 32-wide steps
+    __shared__ float part[4][16][17];
+    const bf16* wp = W + (size_t)nrow * K + kbase + fq * 8;
+    // a wave's weight share stays in registers across the row tiles when it fits 16 steps (K <= 2,048)
+    const bool held = kw <= 512;
+    bf16x8 wreg[16];
+    if (held) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (u * 32 < kw) wreg[u] = *reinterpret_cast<const bf16x8*>(wp + u * 32);
+    }
+    for (int mt = 0; mt * 16 < M; ++mt) {
+        const int mc = min(mt * 16 + fr, M - 1);
+        const bf16* xp = X + (size_t)mc * K + kbase + fq * 8;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (held) {
+#pragma unroll
+            for (int u4 = 0; u4 < 16; u4 += 4) {
+                if (u4 * 32 < kw) {                              // kw is a multiple of 32; whole groups of four while it is one of 128
+                    bf16x8 b[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) b[u] = (u4 + u) * 32 < kw ? *reinterpret_cast<const bf16x8*>(xp + (u4 + u) * 32) : bf16x8{};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if ((u4 + u) * 32 < kw) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[u4 + u], b[u], acc, 0, 0, 0);
+                }
+            }
+        } else {
+            int k = 0;
+            for (; k + 128 <= kw; k += 128) {                    // four steps' loads in flight
+                bf16x8 a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a[u] = *reinterpret_cast<const bf16x8*>(wp + k + 32 * u);
+                    b[u] = *reinterpret_cast<const bf16x8*>(xp + k + 32 * u);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[u], acc, 0, 0, 0);
+            }
+            for (; k < kw; k += 32) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(wp + k);
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(xp + k);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+            }
+        }
+        if (mt > 0) __syncthreads();                             // the previous tile's partial sums have been consumed
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][fr][fq * 4 + r] = acc[r];      // acc[r] = (column n0 + fq * 4 + r, row mt * 16 + fr)
+        __syncthreads();
+        if (wave == 0) {
+            f32x4 sum[1][1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                sum[0][0][r] = ((part[0][fr][fq * 4 + r] + part[1][fr][fq * 4 + r]) + part[2][fr][fq * 4 + r]) + part[3][fr][fq * 4 + r];
+            gemm_epilogue<bf16, EPI, 1, 1>(sum, n0, mt * 16, fr, fq, bias, resid, Cout, M, N, ldc);
+        }
+    }
+}
+
+extern "C" int valle_gemm_skinny(const void* A, const void* W, const void* bias, const void* resid, void* C,
+                                 int M, int N, int K, int ldc, int epilogue, int dtype, void* stream) {
+    VALLE_REQUIRE(A && W && C, VALLE_E_ARG, "valle_gemm_skinny: null pointer");
+    VALLE_REQUIRE(dtype == VALLE_BF16, VALLE_E_UNSUPPORTED, "valle_gemm_skinny: bf16 only (use valle_gemm)");
+    VALLE_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 128 == 0, VALLE_E_ARG, "valle_gemm_skinny: M=%d N=%d K=%d (K must be a multiple of 128)", M, N, K);
+    VALLE_REQUIRE((epilogue != VALLE_EPI_RESID && epilogue != VALLE_EPI_RESID_BIAS) || resid, VALLE_E_ARG, "valle_gemm_skinny: residual missing");
+    VALLE_REQUIRE((epilogue != VALLE_EPI_GELU && epilogue != VALLE_EPI_RESID_BIAS) || bias, VALLE_E_ARG, "valle_gemm_skinny: EPI_GELU / EPI_RESID_BIAS need a bias");
+    VALLE_REQUIRE(ldc >= N, VALLE_E_ARG, "valle_gemm_skinny: ldc %d too small", ldc);
+    if (M == 0) return VALLE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = ceil_div(N, 16);
+#define SK_CASE(E) case E: gemm_skinny_bf16_kernel<E><<<grid, 256, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc); break;
+    switch (epilogue) {
+        SK_CASE(VALLE_EPI_STORE) SK_CASE(VALLE_EPI_RESID) SK_CASE(VALLE_EPI_F32OUT) SK_CASE(VALLE_EPI_GELU) SK_CASE(VALLE_EPI_RESID_BIAS)
+        default: valle_set_error("valle_gemm_skinny: epilogue %d is not built", epilogue); return VALLE_E_ARG;
+    }
+#undef SK_CASE
+    VALLE_LAUNCH_CHECK();
+    return VALLE_OK;
+}
+
 template <typename T>
 static int gemm_dispatch(const void* A, const void* W, const void* bias, const void* resid, void* C,
                          int M, int N, int K, int ldc, int epi, hipStream_t s) {

@@ -322,10 +322,17 @@ class Base_V2(Base):
         L.check(lib.valle_v2_encode_rows(L.ptr(self._bufs["emb"]), e["row0"], e["n_rows"], Lv, L.ptr_any(codes_lm), int(ld), int(n),
                                          L.ptr(e["pos"]), L.ptr(e["nw"]), L.ptr(e["nb"]), L.ptr(y0), L.ptr(src), d, LN_EPS, dt, stream))
         h = torch.empty((rows, e["hdim"]), dtype=self.dtype, device=self.device)
-        L.check(lib.valle_gemm(L.ptr(y0), L.ptr(e["w0"]), L.ptr(e["b0"]), None, L.ptr(h), rows, e["hdim"], d, e["hdim"], L.EPI_GELU, dt, stream))
+        gemm = self._gemm(rows)
+        L.check(gemm(L.ptr(y0), L.ptr(e["w0"]), L.ptr(e["b0"]), None, L.ptr(h), rows, e["hdim"], d, e["hdim"], L.EPI_GELU, dt, stream))
         y = torch.empty((rows, d), dtype=self.dtype, device=self.device)
-        L.check(lib.valle_gemm(L.ptr(h), L.ptr(e["w2"]), L.ptr(e["b2"]), L.ptr(y0), L.ptr(y), rows, d, e["hdim"], d, L.EPI_RESID_BIAS, dt, stream))
+        L.check(gemm(L.ptr(h), L.ptr(e["w2"]), L.ptr(e["b2"]), L.ptr(y0), L.ptr(y), rows, d, e["hdim"], d, L.EPI_RESID_BIAS, dt, stream))
         return y
+
+    SKINNY_ROWS = 256                 # up to this many rows the few-rows GEMM is used in bf16 (a decode step's linears)
+
+    def _gemm(self, rows):
+        lib = L.load()
+        return lib.valle_gemm_skinny if (self.dtype == torch.bfloat16 and rows <= self.SKINNY_ROWS and self.d_model % 128 == 0) else lib.valle_gemm
 
     def place_frames(self, name, y, n, dst, x):
         """The encoder's weighted level sum (base_v2.py:153-157) of n frames into rows dst (device int32) of x."""
@@ -400,15 +407,16 @@ class Base_V2(Base):
             return logits
         t0 = torch.empty((n, d), dtype=self.dtype, device=self.device)
         t2 = torch.empty((n, d), dtype=self.dtype, device=self.device)
+        gemm = self._gemm(n)
         for l, w in enumerate(self._dec):
             t1 = torch.empty((n, w["hdim"]), dtype=self.dtype, device=self.device) if l == 0 or t1.shape[1] != w["hdim"] else t1
             src = hidden
             if w["nw"] is not None:
                 L.check(lib.valle_layernorm(L.ptr(hidden), L.ptr(w["nw"]), L.ptr(w["nb"]), L.ptr(t0), n, d, LN_EPS, dt, stream))
                 src = t0
-            L.check(lib.valle_gemm(L.ptr(src), L.ptr(w["w1"]), L.ptr(w["b1"]), None, L.ptr(t1), n, w["hdim"], d, w["hdim"], L.EPI_GELU, dt, stream))
-            L.check(lib.valle_gemm(L.ptr(t1), L.ptr(w["w3"]), L.ptr(w["b3"]), None, L.ptr(t2), n, d, w["hdim"], d, L.EPI_STORE, dt, stream))
-            L.check(lib.valle_gemm(L.ptr(t2), L.ptr(w["w4"]), L.ptr(w["b4"]), None, L.ptr_any(logits[l]), n, V, d, ld, L.EPI_F32OUT, dt, stream))
+            L.check(gemm(L.ptr(src), L.ptr(w["w1"]), L.ptr(w["b1"]), None, L.ptr(t1), n, w["hdim"], d, w["hdim"], L.EPI_GELU, dt, stream))
+            L.check(gemm(L.ptr(t1), L.ptr(w["w3"]), L.ptr(w["b3"]), None, L.ptr(t2), n, d, w["hdim"], d, L.EPI_STORE, dt, stream))
+            L.check(gemm(L.ptr(t2), L.ptr(w["w4"]), L.ptr(w["b4"]), None, L.ptr_any(logits[l]), n, V, d, ld, L.EPI_F32OUT, dt, stream))
         return logits
 
     def aux_decode(self, name, hidden):
