@@ -341,6 +341,15 @@ def main():
             "roofline": roofline,
             "dense": dense,
         }
+        if dense is not None:
+            # the metric split into its two phases (this rank's times; AR = prefill + KV-cache decode + the
+            # rest of the step's host work, NAR = the seven levels between their two events)
+            ar_ms = ms_per_step - dense["ms"]
+            line["split"] = {"ar_ms": round(ar_ms, 2), "nar_ms": dense["ms"],
+                             "ar_only_level0_frames_per_s": round(B * R / (ar_ms * 1e-3), 1),
+                             "nar_only_frames_per_s": round(B * R / (dense["ms"] * 1e-3), 1),
+                             "rtf_per_utterance": round((elapsed / args.steps) / (R / FRAME_RATE), 5),
+                             "rtf_per_batch": round((elapsed / args.steps) / (B * R / FRAME_RATE), 6)}
         if backend is not None:
             line["collective_backend"] = "rccl" if backend == "nccl" else f"{backend} (ranks share devices: rehearsal, not a scaling number)"
         if world == 1 and not args.no_cpu_baseline:
