@@ -144,6 +144,7 @@ class OracleV2(Oracle):
         remask = kw.get("sampling_scores_remask", False)
         masked_only = kw.pop("sampling_scores_masked_only", False)
         flatten = kw.pop("sampling_scores_flatten", False)
+        trace = kw.pop("trace", None)                                    # list: receives (ids, scores, logits) of every step
         B, Lv = len(lens), self.n_levels
         resps = [torch.full((n, Lv), self.mask_token, dtype=torch.int64) for n in lens]
         scores = [torch.ones((n, Lv), dtype=torch.float32) for n in lens]
@@ -164,6 +165,8 @@ class OracleV2(Oracle):
                 null = self.forward_v2(null_phn, langs, None, resps, timestep=True)
                 logits = self.cfg_v2(logits, null, cfg_strength, lens, cfg_rescale)
             ids, sc = self.sample_v2(logits, lens, temperature=temp, **{k: v for k, v in kw.items() if k in ("top_no",)})
+            if trace is not None:
+                trace.append(([i.clone() for i in ids], [x.clone() for x in sc], [l[..., -n:, :].clone() for l, n in zip(logits, lens)]))
             resps = [torch.where(m, i.t(), r) for m, i, r in zip(is_masked, ids, resps)]
             scores = [torch.where(m, s.t(), torch.ones(())) if masked_only else s.t() for m, s in zip(is_masked, sc)]
             if flatten:
