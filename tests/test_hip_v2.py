@@ -51,7 +51,7 @@ def test_layernorm(gpu_device, dtype, rows, d):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(200, 512, 256), (70, 256, 512), (16, 2048, 1024), (1300, 1024, 2048)])
+@pytest.mark.parametrize("shape", [(200, 512, 256), (70, 256, 512), (16, 2048, 1024), (1300, 1024, 2048), (2300, 2048, 1024)])
 def test_gemm_gelu_and_resid_bias(gpu_device, dtype, shape):
     """The two epilogues of the encoder / decoder FFNs: gelu(A W^T + b) and resid + (A W^T + b)."""
     from vall_e_amd import _lib as L
