@@ -185,16 +185,20 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dist = None
     backend = None
-    if world > 1:
+    # VALLE_BENCH_FORCE_DIST=1: initialise the process group at world size 1 too (rehearses the RCCL calls of the
+    # multi-rank path -- init, barrier, the two all-gathers -- on a one-GPU box)
+    if world > 1 or os.environ.get("VALLE_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         # "nccl" is RCCL on ROCm; VALLE_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs
         # than ranks (ranks then share devices: local_rank % device_count)
         backend = os.environ.get("VALLE_BENCH_BACKEND", "nccl")
-        dist.init_process_group(backend, rank=rank, world_size=world)
     local_rank %= max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)                 # before the process group: RCCL binds the communicator to this GPU
     dev = torch.device("cuda", local_rank)
+    if dist is not None:
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = vcfg.repo_default_model()
     R = args.frames

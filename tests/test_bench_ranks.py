@@ -41,3 +41,21 @@ def test_gpus_flag_must_match_the_launcher(gpu_device):
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
                        env=env, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_rccl_calls_at_world_size_one(gpu_device, tmp_path):
+    """The collective calls of the multi-rank path on the real RCCL backend: VALLE_BENCH_FORCE_DIST=1 initialises the
+    process group at world size 1 (a one-GPU box cannot hold two RCCL ranks), so init, the barriers and the two
+    all-gathers on device tensors run as they do with one GPU per rank; codes equal the run without a process group."""
+    import os
+    one, c1 = _bench(tmp_path, 1, "plain")
+    out = tmp_path / "codes_rccl.npy"
+    env = dict(os.environ, VALLE_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    env.pop("VALLE_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--frames", "10",
+                        "--global-batch", "6", "--no-cpu-baseline", "--dump-codes", str(out)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["collective_backend"] == "rccl" and line["n_gpus"] == 1
+    np.testing.assert_array_equal(c1, np.load(out))
