@@ -312,10 +312,23 @@ int valle_forward_dense(valle_model* m, const int32_t* emb_idx, const int32_t* p
 int valle_gemm_skinny(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K, int ldc,
                       int epilogue, int dtype, void* stream);
 
+/* G products of ONE shape in one launch: group g reads A + g * a_group_stride, W + g * w_group_stride, bias + g *
+ * bias_group_stride, resid + g * resid_group_stride and writes C + g * c_group_stride (strides in ELEMENTS of the operand's
+ * own type: bf16, or fp32 for the bias and C of EPI_F32OUT; A / W strides multiples of 8, resid / C of 4; a stride of 0
+ * shares the operand).  The AudioDecoder's per-level FFNs and heads (models/base_v2.py:199-225: `self.head[level]` applied
+ * level by level) as one launch per linear instead of one per level and linear; every group's arithmetic is valle_gemm_skinny's. */
+int valle_gemm_skinny_grouped(const void* A, size_t a_group_stride, const void* W, size_t w_group_stride, const void* bias,
+                              size_t bias_group_stride, const void* resid, size_t resid_group_stride, void* C,
+                              size_t c_group_stride, int G, int M, int N, int K, int ldc, int epilogue, int dtype, void* stream);
 
 /* nn.LayerNorm over the last dimension (with weight and bias, eps inside the square root): the AudioDecoder's per-level
  * norm (models/base_v2.py:184).  x, w, b, out in dtype. */
 int valle_layernorm(const void* x, const void* w, const void* b, void* out, int rows, int d, float eps, int dtype, void* stream);
+
+/* G LayerNorms of the same rows: w, b = [G][d], out = [G][rows][d] (the per-level norms that open the AudioDecoder's heads,
+ * models/base_v2.py:203-206, in one launch). */
+int valle_layernorm_grouped(const void* x, const void* w, const void* b, void* out, int rows, int d, int G, float eps, int dtype,
+                            void* stream);
 
 /* First half of AudioEncoder.forward (models/base_v2.py:138-147) for n code frames of L <= 32 levels: out[(i * L + l)][:] =
  * LayerNorm(table[row0[l] + codes[l * ld_codes + i]][:] + pos[l][:]) -- codes level-major int32 on the device, table = the

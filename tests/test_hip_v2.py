@@ -334,3 +334,53 @@ def test_gemm_skinny(gpu_device, shape):
         L.check(L.load().valle_gemm_skinny(L.ptr(Ad), L.ptr(Wd), L.ptr(bd), L.ptr(Rp), L.ptr(Cd), M, N, K, ldc, epi, L.BF16, L.stream_ptr()))
         assert rel_l2(Cd[:, :N], want) < (2e-2 if odt == torch.bfloat16 else 2e-5), (epi, shape)
         assert float(Cd[:, N:].abs().max() if ldc > N else 0) == 0.0          # nothing written past N
+
+
+@pytest.mark.parametrize("shared_a", [False, True])
+def test_gemm_skinny_grouped_equals_per_group_calls(gpu_device, shared_a):
+    """valle_gemm_skinny_grouped (G products of one shape in one launch: the AudioDecoder's per-level linears) gives, group
+    by group, the bits of valle_gemm_skinny; every epilogue, a shared (stride 0) or per-group A, ragged N."""
+    from vall_e_amd import _lib as L
+    lib = L.load()
+    G, M, N, K = 8, 16, 1025, 1024
+    ldc = (N + 7) // 8 * 8
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(1 if shared_a else G, M, K, generator=g).bfloat16().to(gpu_device)
+    W = (torch.randn(G, N, K, generator=g) / K ** 0.5).bfloat16().to(gpu_device)
+    bias = 0.3 * torch.randn(G, N, generator=g)
+    R = torch.randn(G, M, ldc, generator=g).bfloat16().to(gpu_device)
+    a_gs = 0 if shared_a else M * K
+    for epi, odt in ((L.EPI_STORE, torch.bfloat16), (L.EPI_GELU, torch.bfloat16), (L.EPI_RESID_BIAS, torch.bfloat16),
+                     (L.EPI_RESID, torch.bfloat16), (L.EPI_F32OUT, torch.float32)):
+        bd = (bias if odt == torch.float32 else bias.bfloat16()).contiguous().to(gpu_device)
+        use_r = epi in (L.EPI_RESID, L.EPI_RESID_BIAS)
+        bp = None if epi == L.EPI_RESID else bd
+        Cg = torch.zeros((G, M, ldc), dtype=odt, device=gpu_device)
+        L.check(lib.valle_gemm_skinny_grouped(L.ptr(A), a_gs, L.ptr(W), N * K, L.ptr(bp), N, L.ptr(R) if use_r else None, M * ldc,
+                                              L.ptr(Cg), M * ldc, G, M, N, K, ldc, epi, L.BF16, L.stream_ptr()))
+        for i in range(G):
+            C1 = torch.zeros((M, ldc), dtype=odt, device=gpu_device)
+            L.check(lib.valle_gemm_skinny(L.ptr(A[0 if shared_a else i]), L.ptr(W[i]), L.ptr(None if bp is None else bp[i]),
+                                          L.ptr(R[i]) if use_r else None, L.ptr(C1), M, N, K, ldc, epi, L.BF16, L.stream_ptr()))
+            assert torch.equal(Cg[i], C1), (epi, i)
+    # group strides that would break the 16-byte fragment loads are refused
+    with pytest.raises(L.ValleHipError):
+        L.check(lib.valle_gemm_skinny_grouped(L.ptr(A), 4, L.ptr(W), N * K, None, 0, None, 0, L.ptr(Cg), M * ldc, G, M, N, K, ldc,
+                                              L.EPI_STORE, L.BF16, L.stream_ptr()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_grouped_equals_per_group_calls(gpu_device, dtype):
+    from vall_e_amd import _lib as L
+    lib = L.load()
+    G, rows, d = 8, 19, 512
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(rows, d, generator=g).to(dtype).to(gpu_device)
+    w = (1 + 0.2 * torch.randn(G, d, generator=g)).to(dtype).to(gpu_device)
+    b = (0.2 * torch.randn(G, d, generator=g)).to(dtype).to(gpu_device)
+    out = torch.zeros((G, rows, d), dtype=dtype, device=gpu_device)
+    L.check(lib.valle_layernorm_grouped(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(out), rows, d, G, 1e-5, L.dtype_code(dtype), L.stream_ptr()))
+    for i in range(G):
+        o1 = torch.zeros((rows, d), dtype=dtype, device=gpu_device)
+        L.check(lib.valle_layernorm(L.ptr(x), L.ptr(w[i]), L.ptr(b[i]), L.ptr(o1), rows, d, 1e-5, L.dtype_code(dtype), L.stream_ptr()))
+        assert torch.equal(out[i], o1), i

@@ -111,6 +111,9 @@ SIGNATURES = {
                                     c_void_p, c_int, c_void_p, c_int, C.c_uint64, C.c_uint64, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p]),
     "valle_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
+    "valle_layernorm_grouped": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "valle_gemm_skinny_grouped": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t,
+                                          c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "valle_v2_encode_rows": (c_int, [c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), c_int, c_void_p, c_int, c_int, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]),
     "valle_v2_level_sum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),

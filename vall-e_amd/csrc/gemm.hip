@@ -682,10 +682,20 @@ extern "C" int valle_gemm_normed(const void* A, const void* Wf, void* C, int M, 
 // of the activation rows likewise (B fragment), the four partial sums meet in LDS.  Weights are read once per 16 rows of M
 // (from L2 behind the first tile).  Used where the caller asks for it (valle_gemm_skinny): the version >= 7 encoder /
 // decoder linears of a decode step.
+// Grouped form (blockIdx.y = group g): G independent products of one shape in one launch -- the eight per-level FFNs and
+// heads of the version >= 7 AudioDecoder (base_v2.py:215-225); every operand of group g lies a fixed stride behind group 0's.
+struct SkinnyGroups { size_t x, w, bias_bytes, resid, c_bytes; };   // strides between groups: elements (x, w, resid) or bytes
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_skinny_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W,
                                                                const void* __restrict__ bias, const bf16* resid, void* Cout,
-                                                               int M, int N, int K, int ldc) {
+                                                               int M, int N, int K, int ldc, SkinnyGroups gs) {
+    {
+        const size_t g = blockIdx.y;
+        X += g * gs.x; W += g * gs.w;
+        if (bias) bias = (const char*)bias + g * gs.bias_bytes;
+        if (resid) resid += g * gs.resid;
+        Cout = (char*)Cout + g * gs.c_bytes;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * 16;
@@ -749,6 +759,19 @@ __global__ __launch_bounds__(256) void gemm_skinny_bf16_kernel(const bf16* __res
     }
 }
 
+static int gemm_skinny_launch(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K,
+                              int ldc, int epilogue, int G, const SkinnyGroups& gs, hipStream_t s) {
+    const dim3 grid(ceil_div(N, 16), G);
+#define SK_CASE(E) case E: gemm_skinny_bf16_kernel<E><<<grid, 256, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc, gs); break;
+    switch (epilogue) {
+        SK_CASE(VALLE_EPI_STORE) SK_CASE(VALLE_EPI_RESID) SK_CASE(VALLE_EPI_F32OUT) SK_CASE(VALLE_EPI_GELU) SK_CASE(VALLE_EPI_RESID_BIAS)
+        default: valle_set_error("valle_gemm_skinny: epilogue %d is not built", epilogue); return VALLE_E_ARG;
+    }
+#undef SK_CASE
+    VALLE_LAUNCH_CHECK();
+    return VALLE_OK;
+}
+
 extern "C" int valle_gemm_skinny(const void* A, const void* W, const void* bias, const void* resid, void* C,
                                  int M, int N, int K, int ldc, int epilogue, int dtype, void* stream) {
     VALLE_REQUIRE(A && W && C, VALLE_E_ARG, "valle_gemm_skinny: null pointer");
@@ -758,16 +781,29 @@ extern "C" int valle_gemm_skinny(const void* A, const void* W, const void* bias,
     VALLE_REQUIRE((epilogue != VALLE_EPI_GELU && epilogue != VALLE_EPI_RESID_BIAS) || bias, VALLE_E_ARG, "valle_gemm_skinny: EPI_GELU / EPI_RESID_BIAS need a bias");
     VALLE_REQUIRE(ldc >= N, VALLE_E_ARG, "valle_gemm_skinny: ldc %d too small", ldc);
     if (M == 0) return VALLE_OK;
-    hipStream_t s = (hipStream_t)stream;
-    const int grid = ceil_div(N, 16);
-#define SK_CASE(E) case E: gemm_skinny_bf16_kernel<E><<<grid, 256, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc); break;
-    switch (epilogue) {
-        SK_CASE(VALLE_EPI_STORE) SK_CASE(VALLE_EPI_RESID) SK_CASE(VALLE_EPI_F32OUT) SK_CASE(VALLE_EPI_GELU) SK_CASE(VALLE_EPI_RESID_BIAS)
-        default: valle_set_error("valle_gemm_skinny: epilogue %d is not built", epilogue); return VALLE_E_ARG;
-    }
-#undef SK_CASE
-    VALLE_LAUNCH_CHECK();
-    return VALLE_OK;
+    return gemm_skinny_launch(A, W, bias, resid, C, M, N, K, ldc, epilogue, 1, SkinnyGroups{}, (hipStream_t)stream);
+}
+
+extern "C" int valle_gemm_skinny_grouped(const void* A, size_t a_group_stride, const void* W, size_t w_group_stride,
+                                         const void* bias, size_t bias_group_stride, const void* resid, size_t resid_group_stride,
+                                         void* C, size_t c_group_stride, int G, int M, int N, int K, int ldc, int epilogue,
+                                         int dtype, void* stream) {
+    VALLE_REQUIRE(A && W && C, VALLE_E_ARG, "valle_gemm_skinny_grouped: null pointer");
+    VALLE_REQUIRE(dtype == VALLE_BF16, VALLE_E_UNSUPPORTED, "valle_gemm_skinny_grouped: bf16 only");
+    VALLE_REQUIRE(G >= 1 && G <= 65535, VALLE_E_ARG, "valle_gemm_skinny_grouped: G=%d", G);
+    VALLE_REQUIRE(M >= 0 && N > 0 && K > 0 && K % 128 == 0, VALLE_E_ARG, "valle_gemm_skinny_grouped: M=%d N=%d K=%d (K must be a multiple of 128)", M, N, K);
+    VALLE_REQUIRE((epilogue != VALLE_EPI_RESID && epilogue != VALLE_EPI_RESID_BIAS) || resid, VALLE_E_ARG, "valle_gemm_skinny_grouped: residual missing");
+    VALLE_REQUIRE((epilogue != VALLE_EPI_GELU && epilogue != VALLE_EPI_RESID_BIAS) || bias, VALLE_E_ARG, "valle_gemm_skinny_grouped: EPI_GELU / EPI_RESID_BIAS need a bias");
+    VALLE_REQUIRE(ldc >= N, VALLE_E_ARG, "valle_gemm_skinny_grouped: ldc %d too small", ldc);
+    // the fragment loads are 16-byte vectors: every group's operands must keep that alignment
+    VALLE_REQUIRE(a_group_stride % 8 == 0 && w_group_stride % 8 == 0 && resid_group_stride % 4 == 0 && c_group_stride % 4 == 0, VALLE_E_ARG,
+                  "valle_gemm_skinny_grouped: group strides must keep 16-byte (A, W) / 8-byte (resid, C) alignment");
+    if (M == 0) return VALLE_OK;
+    SkinnyGroups gs{};
+    gs.x = a_group_stride; gs.w = w_group_stride; gs.resid = resid_group_stride;
+    gs.bias_bytes = bias_group_stride * (epilogue == VALLE_EPI_F32OUT ? sizeof(float) : sizeof(bf16));
+    gs.c_bytes = c_group_stride * (epilogue == VALLE_EPI_F32OUT ? sizeof(float) : sizeof(bf16));
+    return gemm_skinny_launch(A, W, bias, resid, C, M, N, K, ldc, epilogue, G, gs, (hipStream_t)stream);
 }
 
 template <typename T>

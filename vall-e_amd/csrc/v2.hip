@@ -18,6 +18,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
+    // grouped form (blockIdx.y = group): the same rows under another (w, b), written rows * d further on
+    w += (size_t)blockIdx.y * d; b += (size_t)blockIdx.y * d; out += (size_t)blockIdx.y * rows * d;
     const T* xr = GATHER ? x + (size_t)src[r] * d : x + (size_t)r * d;
     const T* pr = GATHER ? pos + (size_t)(r % L) * d : nullptr;
     auto load = [&](int c, float (&f)[VEC]) {
@@ -72,6 +74,24 @@ extern "C" int valle_layernorm(const void* x, const void* w, const void* b, void
         layernorm_kernel<float, false><<<ceil_div(rows, 4), 256, 0, s>>>((const float*)x, nullptr, nullptr, 1, (const float*)w, (const float*)b, (float*)out, rows, d, eps);
     else
         VALLE_REQUIRE(false, VALLE_E_ARG, "valle_layernorm: unknown dtype %d", dtype);
+    VALLE_LAUNCH_CHECK();
+    return VALLE_OK;
+}
+
+// G LayerNorms of the same rows (the AudioDecoder's per-level norms, base_v2.py:203-206): w, b = [G][d], out = [G][rows][d]
+extern "C" int valle_layernorm_grouped(const void* x, const void* w, const void* b, void* out, int rows, int d, int G, float eps,
+                                       int dtype, void* stream) {
+    VALLE_REQUIRE(x && w && b && out, VALLE_E_ARG, "valle_layernorm_grouped: null pointer");
+    VALLE_REQUIRE(rows >= 0 && d > 0 && d % 8 == 0 && G >= 1 && G <= 65535, VALLE_E_ARG, "valle_layernorm_grouped: rows=%d d=%d G=%d", rows, d, G);
+    if (rows == 0) return VALLE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(ceil_div(rows, 4), G);
+    if (dtype == VALLE_BF16)
+        layernorm_kernel<bf16, false><<<grid, 256, 0, s>>>((const bf16*)x, nullptr, nullptr, 1, (const bf16*)w, (const bf16*)b, (bf16*)out, rows, d, eps);
+    else if (dtype == VALLE_F32)
+        layernorm_kernel<float, false><<<grid, 256, 0, s>>>((const float*)x, nullptr, nullptr, 1, (const float*)w, (const float*)b, (float*)out, rows, d, eps);
+    else
+        VALLE_REQUIRE(false, VALLE_E_ARG, "valle_layernorm_grouped: unknown dtype %d", dtype);
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
 }

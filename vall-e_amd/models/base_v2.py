@@ -165,6 +165,18 @@ class Base_V2(Base):
                 w1=up(sd[p + "1.weight"]), b1=up(sd[p + "1.bias"]), w3=up(sd[p + "3.weight"]), b3=up(sd[p + "3.bias"]),
                 w4=up(sd[p + "4.weight"]), b4=sd[p + "4.bias"].to(dt).float().contiguous().to(dev),
                 hdim=int(sd[p + "1.weight"].shape[0])))
+        # levels of one shape (the reference's AudioDecoder builds them so, base_v2.py:199-206) are also kept as ONE tensor per
+        # operand, level-major, so that a few-rows call runs a linear of all levels as one grouped launch (decode below);
+        # the per-level entries become views of it
+        self._decg = None
+        if len({(w["hdim"], tuple(w["w4"].shape)) for w in self._dec}) == 1:
+            g = {k: torch.stack([w[k] for w in self._dec]).contiguous() for k in ("w1", "b1", "w3", "b3", "w4", "b4")}
+            if self.per_level_normalization:
+                g["nw"], g["nb"] = (torch.stack([w[k] for w in self._dec]).contiguous() for k in ("nw", "nb"))
+            for l, w in enumerate(self._dec):
+                for k in g:
+                    w[k] = g[k][l]
+            self._decg = g
         self._aux = {n: (up(sd[f"{n}.head.weight"]), sd[f"{n}.head.bias"].to(dt).float().contiguous().to(dev))
                      for n in ("len_decoder", "phn_decoder", "text_decoder")}
 
@@ -405,9 +417,27 @@ class Base_V2(Base):
         logits = torch.empty((self.n_resp_levels, n, ld), dtype=torch.float32, device=self.device)
         if n == 0:
             return logits
+        gemm = self._gemm(n)
+        g, Lv = self._decg, self.n_resp_levels
+        hd = self._dec[0]["hdim"]
+        if g is not None and gemm is lib.valle_gemm_skinny and hd % 128 == 0:
+            # a decode step's rows: each linear of all levels in one launch (4 launches instead of 4 per level; every level's
+            # arithmetic is the per-level call's)
+            src, a_gs = hidden, 0
+            if "nw" in g:
+                src, a_gs = torch.empty((Lv, n, d), dtype=self.dtype, device=self.device), n * d
+                L.check(lib.valle_layernorm_grouped(L.ptr(hidden), L.ptr(g["nw"]), L.ptr(g["nb"]), L.ptr(src), n, d, Lv, LN_EPS, dt, stream))
+            t1 = torch.empty((Lv, n, hd), dtype=self.dtype, device=self.device)
+            t2 = torch.empty((Lv, n, d), dtype=self.dtype, device=self.device)
+            L.check(lib.valle_gemm_skinny_grouped(L.ptr(src), a_gs, L.ptr(g["w1"]), hd * d, L.ptr(g["b1"]), hd, None, 0, L.ptr(t1), n * hd,
+                                                  Lv, n, hd, d, hd, L.EPI_GELU, dt, stream))
+            L.check(lib.valle_gemm_skinny_grouped(L.ptr(t1), n * hd, L.ptr(g["w3"]), d * hd, L.ptr(g["b3"]), d, None, 0, L.ptr(t2), n * d,
+                                                  Lv, n, d, hd, d, L.EPI_STORE, dt, stream))
+            L.check(lib.valle_gemm_skinny_grouped(L.ptr(t2), n * d, L.ptr(g["w4"]), V * d, L.ptr(g["b4"]), V, None, 0, L.ptr(logits), n * ld,
+                                                  Lv, n, V, d, ld, L.EPI_F32OUT, dt, stream))
+            return logits
         t0 = torch.empty((n, d), dtype=self.dtype, device=self.device)
         t2 = torch.empty((n, d), dtype=self.dtype, device=self.device)
-        gemm = self._gemm(n)
         for l, w in enumerate(self._dec):
             t1 = torch.empty((n, w["hdim"]), dtype=self.dtype, device=self.device) if l == 0 or t1.shape[1] != w["hdim"] else t1
             src = hidden
