@@ -711,7 +711,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_bf16_kernel(const bf16* __res
         for (int u = 0; u < 16; ++u)
             if (u * 32 < kw) wreg[u] = *reinterpret_cast<const bf16x8*>(wp + u * 32);
     }
-    for (int mt = 0; mt * 16 < M; ++mt) {
+    // row tiles of 16: blockIdx.z takes every gridDim.z-th one (few output columns and many rows: the launch fills the chip)
+    const int mt0 = blockIdx.z;
+    for (int mt = mt0; mt * 16 < M; mt += gridDim.z) {
         const int mc = min(mt * 16 + fr, M - 1);
         const bf16* xp = X + (size_t)mc * K + kbase + fq * 8;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -745,7 +747,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_bf16_kernel(const bf16* __res
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
             }
         }
-        if (mt > 0) __syncthreads();                             // the previous tile's partial sums have been consumed
+        if (mt > mt0) __syncthreads();                           // the previous tile's partial sums have been consumed
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[wave][fr][fq * 4 + r] = acc[r];      // acc[r] = (column n0 + fq * 4 + r, row mt * 16 + fr)
         __syncthreads();
@@ -761,7 +763,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_bf16_kernel(const bf16* __res
 
 static int gemm_skinny_launch(const void* A, const void* W, const void* bias, const void* resid, void* C, int M, int N, int K,
                               int ldc, int epilogue, int G, const SkinnyGroups& gs, hipStream_t s) {
-    const dim3 grid(ceil_div(N, 16), G);
+    // the row tiles are dealt to blockIdx.z while the launch has fewer workgroups than the chip has CUs (weights then come
+    // from L2 for all but the first reader; measured on the version >= 7 encoder at 128 rows, see profiles/README.md)
+    const int cols = ceil_div(N, 16) * G, tiles = ceil_div(M, 16);
+    int mz = 256 / cols;
+    mz = mz < 1 ? 1 : (mz > tiles ? tiles : mz);
+    const dim3 grid(ceil_div(N, 16), G, mz);
 #define SK_CASE(E) case E: gemm_skinny_bf16_kernel<E><<<grid, 256, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc, gs); break;
     switch (epilogue) {
         SK_CASE(VALLE_EPI_STORE) SK_CASE(VALLE_EPI_RESID) SK_CASE(VALLE_EPI_F32OUT) SK_CASE(VALLE_EPI_GELU) SK_CASE(VALLE_EPI_RESID_BIAS)
