@@ -62,6 +62,22 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[NI][MJ], int nw0, int
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int nb = nw0 + i * 16 + fq * 4;
+        // the four columns' bias once per column group (one 8-byte load; it does not depend on the row tile j)
+        [[maybe_unused]] float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI == VALLE_EPI_RESID_BIAS || EPI == VALLE_EPI_GELU || EPI == VALLE_EPI_STORE) {
+            const T* bt = (const T*)bias;
+            if (bt != nullptr && nb < N) {
+                if (nb + 3 < N && sizeof(T) == 2 && (reinterpret_cast<uintptr_t>(bt) & 7) == 0) {
+                    typedef T vec4 __attribute__((ext_vector_type(4)));
+                    const vec4 b4 = *reinterpret_cast<const vec4*>(bt + nb);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bv[r] = to_f32<T>(b4[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bv[r] = nb + r < N ? to_f32<T>(bt[nb + r]) : 0.f;
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
             const int m = mw0 + j * 16 + fr;
@@ -83,7 +99,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[NI][MJ], int nw0, int
                 *reinterpret_cast<vec2*>(C + (size_t)m * ldc + (nb >> 1)) = o;
             } else {
                 T* C = (T*)Cout;
-                const T* bt = (const T*)bias;
                 if (nb + 3 < N && (ldc & 3) == 0) {
                     typedef T vec4 __attribute__((ext_vector_type(4)));
                     vec4 o;
@@ -94,13 +109,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[NI][MJ], int nw0, int
                     } else if constexpr (EPI == VALLE_EPI_RESID_BIAS) {
                         const vec4 rr = *reinterpret_cast<const vec4*>(resid + (size_t)m * ldc + nb);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(to_f32<T>(rr[r]) + to_f32<T>(from_f32<T>(v[r] + to_f32<T>(bt[nb + r]))));
+                        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(to_f32<T>(rr[r]) + to_f32<T>(from_f32<T>(v[r] + bv[r])));
                     } else if constexpr (EPI == VALLE_EPI_GELU) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(gelu_erf(to_f32<T>(from_f32<T>(v[r] + to_f32<T>(bt[nb + r])))));
+                        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(gelu_erf(to_f32<T>(from_f32<T>(v[r] + bv[r]))));
                     } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r] + (bt ? to_f32<T>(bt[nb + r]) : 0.f));
+                        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r] + bv[r]);
                     }
                     *reinterpret_cast<vec4*>(C + (size_t)m * ldc + nb) = o;
                 } else {
@@ -109,9 +124,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[NI][MJ], int nw0, int
                         if (nb + r >= N) continue;
                         float o = v[r];
                         if constexpr (EPI == VALLE_EPI_RESID) o = to_f32<T>(resid[(size_t)m * ldc + nb + r]) + to_f32<T>(from_f32<T>(o));
-                        else if constexpr (EPI == VALLE_EPI_RESID_BIAS) o = to_f32<T>(resid[(size_t)m * ldc + nb + r]) + to_f32<T>(from_f32<T>(o + to_f32<T>(bt[nb + r])));
-                        else if constexpr (EPI == VALLE_EPI_GELU) o = gelu_erf(to_f32<T>(from_f32<T>(o + to_f32<T>(bt[nb + r]))));
-                        else if (bt) o += to_f32<T>(bt[nb + r]);
+                        else if constexpr (EPI == VALLE_EPI_RESID_BIAS) o = to_f32<T>(resid[(size_t)m * ldc + nb + r]) + to_f32<T>(from_f32<T>(o + bv[r]));
+                        else if constexpr (EPI == VALLE_EPI_GELU) o = gelu_erf(to_f32<T>(from_f32<T>(o + bv[r])));
+                        else if constexpr (EPI == VALLE_EPI_STORE) o += bv[r];
                         C[(size_t)m * ldc + nb + r] = from_f32<T>(o);
                     }
                 }
@@ -597,6 +612,25 @@ static int gemm_glds_dispatch(const void* A, const void* W, const void* bias, co
             dim3 g256(nx, ceil_div(M, 256));
             gemm_pp256_bf16_kernel<VALLE_EPI_RESID><<<g256, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
         }
+        VALLE_LAUNCH_CHECK();
+        return VALLE_OK;
+    }
+    // the second linear of the version >= 7 encoder FFN (bias + residual, base_v2.py:120-134) at dense-pass row counts: the
+    // ping-pong tiles, 192 or 256 rows by rounds (57,600 x 1,024 x 2,048: 381 -> 324 us; NAR-len of all levels 383.0 -> 380.8
+    // ms).  The GELU linear was tried on them too: 570 -> 497 us alone on random operands, but 383 -> 385 ms in the NAR-len
+    // run (the erf of every output sets the pace on real activations) -- left on the 128 x 128 tiles; bias alone likewise
+    // (N = d_model at 7,200 rows: 45 us there against 51 here).
+    if (epi == VALLE_EPI_RESID_BIAS && K >= 1024 && M >= 2048 && N >= 256) {
+        const int nx = ceil_div(N, 256);
+        const float r256 = (float)ceil_div(nx * ceil_div(M, 256), 256), r192 = 0.85f * (float)ceil_div(nx * ceil_div(M, 192), 256);
+        const bool t192 = r192 < r256;
+        const dim3 g(nx, ceil_div(M, t192 ? 192 : 256));
+#define PP_CASE(E) case E: \
+        if (t192) gemm_pp256_bf16_kernel<E, false, 48><<<g, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc); \
+        else gemm_pp256_bf16_kernel<E><<<g, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc); \
+        break;
+        switch (epi) { PP_CASE(VALLE_EPI_RESID_BIAS) }
+#undef PP_CASE
         VALLE_LAUNCH_CHECK();
         return VALLE_OK;
     }
