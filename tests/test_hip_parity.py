@@ -1477,3 +1477,69 @@ def test_checkpoint_file_in_published_shape_loads_and_runs(gpu_device, tmp_path)
     ar2 = tts2.model(**kw, max_duration=7, temperature=0.0)
     for b in range(3):
         assert torch.equal(ar2[b], ar[b])
+
+
+@pytest.mark.parametrize("top_k,top_p,decay", [(50, 0.9, 0.0), (50, 0.9, 0.5), (1, 0.5, 0.0), (64, 0.3, 0.0), (200, 0.9, 0.0), (0, 0.9, 0.0), (5, 1.0, 0.0)])
+def test_sampler_processed_rows_vs_oracle(gpu_device, top_k, top_p, decay):
+    """The WHOLE processed row (not only its arg-max) of the sampler chain against the oracle's restatement of
+    samplers.py: repetition penalty on a 2,000-token history with many repeats (decay 0 goes through the counting form,
+    decay > 0 through the ordered one), length penalty, top-k (radix select), top-p (the sorted <= 64-column form behind
+    a small top-k, the search otherwise; tied logits included).  The rows come back through valle_beam_pick's scratch."""
+    from vall_e_amd import _lib as L
+    import valle_oracle as vo
+    m = hip_model("tiny")
+    lib = L.load()
+    rows, V, ld, n_prev = 8, 1025, 1032, 2000
+    g = torch.Generator().manual_seed(top_k * 7 + int(top_p * 10))
+    lg = (torch.randn(rows, V, generator=g) * 3).float()
+    lg[:, 100:140] = lg[:, 99:100]                                   # a run of tied logits across the top-k boundary region
+    lg[0, :60] = 9.0                                                 # more ties than lanes at the top
+    prev = torch.randint(0, 90, (rows, n_prev), generator=g)         # few distinct tokens: every one repeats ~20 times
+    prev[:, ::7] = 1024                                              # the stop token among them (length penalty acts on it)
+    buf = torch.zeros((rows, ld)); buf[:, :V] = lg
+    seq = prev.int().contiguous().to(gpu_device)
+    seq_len = torch.full((rows,), n_prev, dtype=torch.int32, device=gpu_device)
+    sp = m.sample_params(temperature=0.0, top_no=0.0, top_k=top_k, top_p=top_p, repetition_penalty=1.2, repetition_penalty_decay=decay,
+                         length_penalty=0.3)
+    proc = torch.zeros((rows, ld), device=gpu_device)
+    forced = torch.zeros((rows, ld), device=gpu_device)
+    ids = torch.zeros(rows, dtype=torch.int32, device=gpu_device)
+    sc = torch.zeros(rows, device=gpu_device)
+    L.check(lib.valle_beam_pick(L.ptr(buf.to(gpu_device)), ld, V, rows, 1, C.byref(sp), L.ptr(seq), n_prev, L.ptr(seq_len),
+                                L.ptr(proc), L.ptr(forced), L.ptr(ids), L.ptr(sc), L.stream_ptr()))
+    got = proc.cpu()[:, :V]
+    # the pick itself marks the one candidate it took (the largest entry of the matrix) with -inf: put its value back
+    tok, best = int(ids[0]), float(sc[0])
+    want = []
+    for r in range(rows):
+        w = lg[r:r + 1].clone()
+        w = vo.repetition_penalize(w, prev[r], 1.2, decay)
+        w = vo.length_penalize(w, n_prev + 1, 0.3, 1024)
+        want.append(vo.top_k_top_p_filter(w, top_k, top_p)[0])
+    assert best >= float(got.max())
+    taken = [r for r in range(rows) if got[r, tok] == float("-inf") and abs(float(want[r][tok]) - best) <= 2e-6 * abs(best)]
+    assert len(taken) >= 1
+    got[taken[0], tok] = best
+    for r in range(rows):
+        w = want[r]
+        keep_w, keep_g = torch.isfinite(w), torch.isfinite(got[r])
+        # the kept set: identical, except that a column whose preceding mass sits within rounding of top_p may fall either way
+        only_w, only_g = keep_w & ~keep_g, keep_g & ~keep_w
+        if bool(only_w.any()) and torch.equal(torch.sort(w[only_w]).values, torch.sort(got[r][only_g]).values):
+            # tied logits across the top-p cut: the reference's torch.sort is not stable, so WHICH of the tied columns stay
+            # is its sort's accident (here: the lower index first); the number kept and their values are the same
+            keep_w = keep_g = keep_w & keep_g
+        if not torch.equal(keep_w, keep_g):
+            diff = (keep_w != keep_g).nonzero()[:, 0]
+            p = torch.softmax(torch.where(torch.isfinite(w) | keep_g, torch.maximum(w, got[r]), w), -1)
+            srt = torch.sort(torch.maximum(w, got[r]), descending=True)
+            cum = torch.cumsum(torch.softmax(srt.values, -1), -1)
+            for c in diff.tolist():
+                pos_c = int((srt.indices == c).nonzero()[0, 0])
+                before = float(cum[pos_c - 1]) if pos_c > 0 else 0.0
+                assert abs(before - top_p) < 1e-5, (r, c, before)
+        both = keep_w & keep_g
+        if decay == 0.0:
+            assert torch.equal(w[both], got[r][both]), r                  # the same divisions in the same order
+        else:
+            torch.testing.assert_close(got[r][both], w[both], rtol=2e-6, atol=0)   # pow() in double on either side
