@@ -441,7 +441,12 @@ __global__ __launch_bounds__(256) void gemm_glds_n64_bf16_kernel(const bf16* __r
 // (vmcnt(0)) in the 4th read slot, two barriers before its first read.
 // MQR = m rows per wave: 64 (256-row tiles) or 48 (192-row tiles: the second B half is one 16-row tile instead of two --
 // for row counts whose 256-row tiling leaves CUs idle, see gemm_glds_dispatch)
-template <int EPI, bool NORM = false, int MQR = 64>
+// PERSIST: a one-dimensional grid of at most one workgroup per CU, every workgroup walks tiles t = blockIdx.x, + gridDim.x, ...
+// (t = n tile + n tiles x m tile, the order a two-dimensional grid is dispatched in).  The first K-tile of the NEXT output
+// tile is staged during the last K-tile of this one (its buffer is free by then) and the second one behind the last reads,
+// in front of the epilogue, so a tile after the first starts without a dispatch, without a cold prologue and with the
+// epilogue's stores still in flight.  K / 64 must be even (the buffers alternate across the tile boundary).
+template <int EPI, bool NORM = false, int MQR = 64, bool PERSIST = false>
 __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W,
                                                               const void* __restrict__ bias, const bf16* resid,
                                                               void* Cout, int M, int N, int K, int ldc, float eps = 0.f) {
@@ -453,24 +458,28 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
     const int fr = lane & 15, fq = lane >> 4;
     static_assert(MQR == 64 || MQR == 48, "m rows per wave");
     constexpr int TMR = 4 * MQR, MJ = MQR / 16, PPW = (32 + TMR / 8) / 8;    // tile rows, 16-row m tiles per wave, pieces per wave
-    const int n0 = blockIdx.x * 256, m0 = blockIdx.y * TMR;
+    const int nxt = (N + 255) >> 8;                                        // n tiles (PERSIST)
+    [[maybe_unused]] const int ntiles = nxt * ((M + TMR - 1) / TMR);
+    int tile = blockIdx.x;
+    int n0, m0;
+    if constexpr (PERSIST) { n0 = (tile % nxt) * 256; m0 = (tile / nxt) * TMR; }
+    else { n0 = blockIdx.x * 256; m0 = blockIdx.y * TMR; }
 
     f32x4 acc[8][MJ];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // staging: a K-tile is 64 pieces of 8 rows (W: 0..31, X: 32..63); this wave issues pieces wave*8 .. +7
     const bf16* src[8];
+    auto set_src = [&](int tn0, int tm0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int piece = wave * PPW + (j < PPW ? j : PPW - 1);
-        const int row = piece * 8 + (lane >> 3);                           // 0..255 W rows, 256..256+TMR-1 X rows
-        const int ch = (lane & 7) ^ (row & 7);
-        if (piece < 32) { int n = n0 + row; n = n < N ? n : N - 1; src[j] = W + (size_t)n * K + ch * 8; }
-        else { int m = m0 + row - 256; m = m < M ? m : M - 1; src[j] = X + (size_t)m * K + ch * 8; }
-    }
+        for (int j = 0; j < 8; ++j) {
+            const int piece = wave * PPW + (j < PPW ? j : PPW - 1);
+            const int row = piece * 8 + (lane >> 3);                       // 0..255 W rows, 256..256+TMR-1 X rows
+            const int ch = (lane & 7) ^ (row & 7);
+            if (piece < 32) { int n = tn0 + row; n = n < N ? n : N - 1; src[j] = W + (size_t)n * K + ch * 8; }
+            else { int m = tm0 + row - 256; m = m < M ? m : M - 1; src[j] = X + (size_t)m * K + ch * 8; }
+        }
+    };
+    set_src(n0, m0);
     auto stage_part = [&](int kt, int buf, int j0, int j1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -525,6 +534,18 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
     // epilogue through LDS
     constexpr int RPT = TMR * 16 / 512;
     [[maybe_unused]] f32x4 rrow[RPT];
+    const int nt = K / 64;
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  for (;;) {                                                               // tiles of this workgroup (one unless PERSIST)
+    [[maybe_unused]] const bool has_next = PERSIST && tile + (int)gridDim.x < ntiles;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (NORM) { ssq[0] = ssq[1] = ssq[2] = ssq[3] = 0.f; }
     if constexpr (EPI == GEMM_EPI_ROPE) {
         const int32_t* pos = reinterpret_cast<const int32_t*>(resid);
         const float* tab = reinterpret_cast<const float*>(bias);
@@ -535,31 +556,34 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
             rrow[t] = *reinterpret_cast<const f32x4*>(tab + (size_t)pos[m] * 64 + (idx & 15) * 4);
         }
     }
-    const int nt = K / 64;
-    stage(0, 0);
-    if (nt > 1) stage(1, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();                            // group 1 runs one slot behind
     for (int kt = 0; kt < nt; ++kt) {
         const char* L = lds + (kt & 1) * 65536;
         // tile kt+1 goes into the OTHER buffer, whose last reads (tile kt-1) ended before this iteration began;
         // its 8 DMA pieces per wave are spread over the read slots (a piece costs ~60-100 cycles to issue)
-        const bool st = kt >= 1 && kt + 1 < nt;
+        bool st = kt >= 1 && kt + 1 < nt;
+        int ktn = kt + 1;
+        if constexpr (PERSIST) {
+            if (has_next && kt + 1 == nt) {                                // K-tile 0 of the NEXT output tile (nt is even: buffer 0)
+                const int t2 = tile + (int)gridDim.x;
+                set_src((t2 % nxt) * 256, (t2 / nxt) * TMR);
+                st = true; ktn = 0;
+            }
+        }
         read_a(L, 0); read_b(L, 0, B0);                                   // R1
-        if (st) stage_part(kt + 1, (kt + 1) & 1, 0, 2);
+        if (st) stage_part(ktn, (kt + 1) & 1, 0, 2);
         PP_END_READ();
         quad(0, 0, B0);                                                   // M1
         sq_b(0, B0);
         PP_END_MFMA();
         read_b(L, 1, B1);                                                 // R2
-        if (st) stage_part(kt + 1, (kt + 1) & 1, 2, 5);
+        if (st) stage_part(ktn, (kt + 1) & 1, 2, 5);
         PP_END_READ();
         quad(0, 1, B1);                                                   // M2
         sq_b(1, B1);
         PP_END_MFMA();
         read_a(L, 1);                                                     // R3
-        if (st) stage_part(kt + 1, (kt + 1) & 1, 5, 8);
+        if (st) stage_part(ktn, (kt + 1) & 1, 5, 8);
         PP_END_READ();
         quad(1, 1, B1);                                                   // M3
         PP_END_MFMA();
@@ -569,8 +593,9 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
         PP_END_MFMA();
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
-#undef PP_END_READ
-#undef PP_END_MFMA
+    // PERSIST: every wave's pieces of the next tile's K-tile 0 have landed in buffer 0 (own vmcnt(0) in R4, then barriers) and
+    // buffer 1 has been read for the last time: its K-tile 1 goes out now, in front of the epilogue's stores
+    if constexpr (PERSIST && EPI != GEMM_EPI_ROPE) { if (has_next) stage(1, 1); }
     if constexpr (NORM) {
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
@@ -580,7 +605,10 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
         }
     }
     if constexpr (EPI == GEMM_EPI_ROPE) {
-        float* rope_rows = reinterpret_cast<float*>(lds);                  // TMR x 68 floats (<= 70 KB of the 128 KB)
+        // TMR x 68 floats: 52 KB at 192-row tiles, 70 KB at 256.  PERSIST (192-row tiles only): in buffer 1, buffer 0 holds
+        // the next tile's K-tile 0; K-tile 1 is staged once every wave has taken its rows
+        static_assert(!PERSIST || TMR * 68 * 4 <= 65536, "RoPE rows of a persistent tile must fit one buffer");
+        float* rope_rows = reinterpret_cast<float*>(lds + (PERSIST ? 65536 : 0));
         __syncthreads();                                                   // the last tile has been read by every wave
 #pragma unroll
         for (int t = 0; t < RPT; ++t) {
@@ -589,9 +617,38 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
         }
         __syncthreads();
         gemm_epilogue<bf16, EPI, 8, MJ>(acc, n0 + nh * 128, m0 + mq * MQR, fr, fq, bias, resid, Cout, M, N, ldc, rope_rows + mq * MQR * 68);
+        if constexpr (PERSIST) {
+            if (has_next) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                stage(1, 1);
+            }
+        }
     } else {
         gemm_epilogue<bf16, EPI, 8, MJ>(acc, n0 + nh * 128, m0 + mq * MQR, fr, fq, bias, resid, Cout, M, N, ldc);
     }
+    if constexpr (!PERSIST) break;
+    else {
+        if (!has_next) break;
+        tile += (int)gridDim.x;
+        n0 = (tile % nxt) * 256; m0 = (tile / nxt) * TMR;
+    }
+  }
+#undef PP_END_READ
+#undef PP_END_MFMA
+}
+
+// Persistent form of the ping-pong kernel: when a launch is several rounds of one-workgroup-per-CU tiles and K / 64 is even.
+// VALLE_GEMM_PERSIST=0 (dev switch, read once) keeps the one-tile-per-workgroup launches for A/B runs.
+static int pp_persist_grid(int ntiles, int K) {
+    static const int enabled = [] { const char* e = getenv("VALLE_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    if (!enabled || ntiles <= n_cu || (K / 64) % 2 != 0 || K < 128) return 0;
+    return n_cu;
 }
 
 static int gemm_glds_dispatch(const void* A, const void* W, const void* bias, const void* resid, void* C,
@@ -687,7 +744,9 @@ extern "C" int valle_gemm_normed(const void* A, const void* Wf, void* C, int M, 
     const bf16* X = (const bf16*)A; const bf16* W = (const bf16*)Wf;
     if (epilogue == VALLE_EPI_GEGLU && N >= 4096 && M >= 1024) {
         dim3 g256(ceil_div(N, 256), ceil_div(M, 256));
-        gemm_pp256_bf16_kernel<VALLE_EPI_GEGLU, true><<<g256, 512, 0, s>>>(X, W, nullptr, nullptr, C, M, N, K, ldc, eps);
+        const int pg = pp_persist_grid(g256.x * g256.y, K);
+        if (pg) gemm_pp256_bf16_kernel<VALLE_EPI_GEGLU, true, 64, true><<<pg, 512, 0, s>>>(X, W, nullptr, nullptr, C, M, N, K, ldc, eps);
+        else gemm_pp256_bf16_kernel<VALLE_EPI_GEGLU, true><<<g256, 512, 0, s>>>(X, W, nullptr, nullptr, C, M, N, K, ldc, eps);
     } else {
         dim3 grid(ceil_div(N, 128), ceil_div(M, 128));
         if (epilogue == VALLE_EPI_GEGLU) gemm_glds_bf16_kernel<VALLE_EPI_GEGLU, true><<<grid, 256, 0, s>>>(X, W, nullptr, nullptr, C, M, N, K, ldc, eps);
@@ -698,7 +757,9 @@ extern "C" int valle_gemm_normed(const void* A, const void* Wf, void* C, int M, 
             const float frac = rounds - (float)(int)rounds;
             if (rounds >= 2.f && (frac == 0.f || frac > 0.7f)) {
                 dim3 g192(N / 256, ceil_div(M, 192));
-                gemm_pp256_bf16_kernel<GEMM_EPI_ROPE, true, 48><<<g192, 512, 0, s>>>(X, W, rope, (const bf16*)pos, C, M, N, K, ldc, eps);
+                const int pg = pp_persist_grid(g192.x * g192.y, K);
+                if (pg) gemm_pp256_bf16_kernel<GEMM_EPI_ROPE, true, 48, true><<<pg, 512, 0, s>>>(X, W, rope, (const bf16*)pos, C, M, N, K, ldc, eps);
+                else gemm_pp256_bf16_kernel<GEMM_EPI_ROPE, true, 48><<<g192, 512, 0, s>>>(X, W, rope, (const bf16*)pos, C, M, N, K, ldc, eps);
             } else {
                 gemm_glds_bf16_kernel<GEMM_EPI_ROPE, true><<<grid, 256, 0, s>>>(X, W, rope, (const bf16*)pos, C, M, N, K, ldc, eps);
             }
