@@ -662,12 +662,17 @@ static int gemm_glds_dispatch(const void* A, const void* W, const void* bias, co
         // 192 workgroups of 256 rows leave 64 CUs idle, 256 workgroups of 192 rows fill the chip)
         const int nx = ceil_div(N, 256);
         const float r256 = (float)ceil_div(nx * ceil_div(M, 256), 256), r192 = 0.85f * (float)ceil_div(nx * ceil_div(M, 192), 256);
+        // (several rounds -- the NAR-len pass of 64 utterances has 4 -- run as one persistent launch)
         if (r192 < r256) {
             dim3 g192(nx, ceil_div(M, 192));
-            gemm_pp256_bf16_kernel<VALLE_EPI_RESID, false, 48><<<g192, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
+            const int pg = pp_persist_grid(g192.x * g192.y, K);
+            if (pg) gemm_pp256_bf16_kernel<VALLE_EPI_RESID, false, 48, true><<<pg, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
+            else gemm_pp256_bf16_kernel<VALLE_EPI_RESID, false, 48><<<g192, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
         } else {
             dim3 g256(nx, ceil_div(M, 256));
-            gemm_pp256_bf16_kernel<VALLE_EPI_RESID><<<g256, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
+            const int pg = pp_persist_grid(g256.x * g256.y, K);
+            if (pg) gemm_pp256_bf16_kernel<VALLE_EPI_RESID, false, 64, true><<<pg, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
+            else gemm_pp256_bf16_kernel<VALLE_EPI_RESID><<<g256, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
         }
         VALLE_LAUNCH_CHECK();
         return VALLE_OK;
@@ -682,8 +687,11 @@ static int gemm_glds_dispatch(const void* A, const void* W, const void* bias, co
         const float r256 = (float)ceil_div(nx * ceil_div(M, 256), 256), r192 = 0.85f * (float)ceil_div(nx * ceil_div(M, 192), 256);
         const bool t192 = r192 < r256;
         const dim3 g(nx, ceil_div(M, t192 ? 192 : 256));
+        const int pg = pp_persist_grid(g.x * g.y, K);
 #define PP_CASE(E) case E: \
-        if (t192) gemm_pp256_bf16_kernel<E, false, 48><<<g, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc); \
+        if (t192 && pg) gemm_pp256_bf16_kernel<E, false, 48, true><<<pg, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc); \
+        else if (t192) gemm_pp256_bf16_kernel<E, false, 48><<<g, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc); \
+        else if (pg) gemm_pp256_bf16_kernel<E, false, 64, true><<<pg, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc); \
         else gemm_pp256_bf16_kernel<E><<<g, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc); \
         break;
         switch (epi) { PP_CASE(VALLE_EPI_RESID_BIAS) }
@@ -702,7 +710,10 @@ static int gemm_glds_dispatch(const void* A, const void* W, const void* bias, co
     // 256 workgroups (gate/up: +12 % over the 128^2 kernel) and loses on the QKV shape (2.25 rounds: -10 %).
     if (N >= 4096 && M >= 1024 && (epi == VALLE_EPI_STORE || epi == VALLE_EPI_GEGLU)) {
         dim3 g256(ceil_div(N, 256), ceil_div(M, 256));
-        if (epi == VALLE_EPI_STORE) gemm_pp256_bf16_kernel<VALLE_EPI_STORE><<<g256, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
+        const int pg = pp_persist_grid(g256.x * g256.y, K);
+        if (epi == VALLE_EPI_STORE && pg) gemm_pp256_bf16_kernel<VALLE_EPI_STORE, false, 64, true><<<pg, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
+        else if (epi == VALLE_EPI_STORE) gemm_pp256_bf16_kernel<VALLE_EPI_STORE><<<g256, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
+        else if (pg) gemm_pp256_bf16_kernel<VALLE_EPI_GEGLU, false, 64, true><<<pg, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
         else gemm_pp256_bf16_kernel<VALLE_EPI_GEGLU><<<g256, 512, 0, s>>>((const bf16*)A, (const bf16*)W, bias, (const bf16*)resid, C, M, N, K, ldc);
         VALLE_LAUNCH_CHECK();
         return VALLE_OK;
