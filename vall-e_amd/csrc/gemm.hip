@@ -446,6 +446,9 @@ __global__ __launch_bounds__(256) void gemm_glds_n64_bf16_kernel(const bf16* __r
 // tile is staged during the last K-tile of this one (its buffer is free by then) and the second one behind the last reads,
 // in front of the epilogue, so a tile after the first starts without a dispatch, without a cold prologue and with the
 // epilogue's stores still in flight.  K / 64 must be even (the buffers alternate across the tile boundary).
+#ifndef PP_SWZ_MAX_NX
+#define PP_SWZ_MAX_NX 16
+#endif
 template <int EPI, bool NORM = false, int MQR = 64, bool PERSIST = false>
 __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W,
                                                               const void* __restrict__ bias, const bf16* resid,
@@ -458,12 +461,21 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
     const int fr = lane & 15, fq = lane >> 4;
     static_assert(MQR == 64 || MQR == 48, "m rows per wave");
     constexpr int TMR = 4 * MQR, MJ = MQR / 16, PPW = (32 + TMR / 8) / 8;    // tile rows, 16-row m tiles per wave, pieces per wave
-    const int nxt = (N + 255) >> 8;                                        // n tiles (PERSIST)
-    [[maybe_unused]] const int ntiles = nxt * ((M + TMR - 1) / TMR);
-    int tile = blockIdx.x;
+    // Tile t (in dispatch order; workgroup b lands on XCD b mod 8) -> (n tile, m tile).  Few n tiles (o_proj / down_proj: 4,
+    // q/k/v: 12): the plain order n = t mod nxt deals the workgroups that share an m tile's activation rows to as many XCDs
+    // as there are n tiles, and every one of those L2s fetches the rows (down_proj at 12,176 rows: 441 MB over the fabric for
+    // 108 MB of operands); instead XCD x takes the m tiles x, x + 8, ... with ALL their n tiles, so a row tile is fetched once.
+    // (Many n tiles -- gate/up: 32 -- keep the plain order: 8 m tiles x 4 n tiles per XCD and round is the smaller footprint.)
+    const int nxt = (N + 255) >> 8, nyt = (M + TMR - 1) / TMR;
+    [[maybe_unused]] const int ntiles = nxt * nyt;
+    const int nswz = nxt <= PP_SWZ_MAX_NX ? nxt * (nyt & ~7) : 0;          // tiles [0, nswz) are dealt by XCD
+    auto tile_nm = [&](int t, int& tn0, int& tm0) {
+        if (t < nswz) { const int sl = t >> 3; tn0 = (sl % nxt) * 256; tm0 = ((t & 7) + 8 * (sl / nxt)) * TMR; }
+        else { tn0 = (t % nxt) * 256; tm0 = (t / nxt) * TMR; }
+    };
+    int tile = PERSIST ? (int)blockIdx.x : (int)(blockIdx.x + gridDim.x * blockIdx.y);
     int n0, m0;
-    if constexpr (PERSIST) { n0 = (tile % nxt) * 256; m0 = (tile / nxt) * TMR; }
-    else { n0 = blockIdx.x * 256; m0 = blockIdx.y * TMR; }
+    tile_nm(tile, n0, m0);
 
     f32x4 acc[8][MJ];
 
@@ -565,8 +577,9 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
         int ktn = kt + 1;
         if constexpr (PERSIST) {
             if (has_next && kt + 1 == nt) {                                // K-tile 0 of the NEXT output tile (nt is even: buffer 0)
-                const int t2 = tile + (int)gridDim.x;
-                set_src((t2 % nxt) * 256, (t2 / nxt) * TMR);
+                int n2, m2;
+                tile_nm(tile + (int)gridDim.x, n2, m2);
+                set_src(n2, m2);
                 st = true; ktn = 0;
             }
         }
@@ -631,7 +644,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
     else {
         if (!has_next) break;
         tile += (int)gridDim.x;
-        n0 = (tile % nxt) * 256; m0 = (tile / nxt) * TMR;
+        tile_nm(tile, n0, m0);
     }
   }
 #undef PP_END_READ
