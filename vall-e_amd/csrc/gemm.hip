@@ -453,7 +453,9 @@ template <int EPI, bool NORM = false, int MQR = 64, bool PERSIST = false>
 __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W,
                                                               const void* __restrict__ bias, const bf16* resid,
                                                               void* Cout, int M, int N, int K, int ldc, float eps = 0.f) {
-    __shared__ __attribute__((aligned(1024))) char lds[2 * 65536];        // [buf][W 256 rows | X 256 rows] x 128 B
+    // [buf][W 256 rows | X 256 rows] x 128 B; behind them, in the persistent RoPE form, what the tile's (cos, sin) rows need beyond buffer 1
+    constexpr int ROPE_TAIL = (EPI == GEMM_EPI_ROPE && PERSIST && MQR * 4 * 68 * 4 > 65536) ? MQR * 4 * 68 * 4 - 65536 : 0;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * 65536 + ROPE_TAIL];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wi = wave & 3;
@@ -618,9 +620,8 @@ __global__ __launch_bounds__(512) void gemm_pp256_bf16_kernel(const bf16* __rest
         }
     }
     if constexpr (EPI == GEMM_EPI_ROPE) {
-        // TMR x 68 floats: 52 KB at 192-row tiles, 70 KB at 256.  PERSIST (192-row tiles only): in buffer 1, buffer 0 holds
-        // the next tile's K-tile 0; K-tile 1 is staged once every wave has taken its rows
-        static_assert(!PERSIST || TMR * 68 * 4 <= 65536, "RoPE rows of a persistent tile must fit one buffer");
+        // TMR x 68 floats: 52 KB at 192-row tiles, 70 KB at 256.  PERSIST: from buffer 1 on (buffer 0 holds the next tile's
+        // K-tile 0; 256-row tiles run 4 KB past buffer 1 into ROPE_TAIL); K-tile 1 is staged once every wave has taken its rows
         float* rope_rows = reinterpret_cast<float*>(lds + (PERSIST ? 65536 : 0));
         __syncthreads();                                                   // the last tile has been read by every wave
 #pragma unroll
@@ -779,7 +780,14 @@ extern "C" int valle_gemm_normed(const void* A, const void* Wf, void* C, int M, 
             // 12 x 64 = 3.0 rounds, 95 vs 105 us without the epilogue); else the 128 x 128 kernel
             const float rounds = N % 256 == 0 ? (float)(N / 256) * (float)ceil_div(M, 192) / 256.f : 0.f;
             const float frac = rounds - (float)(int)rounds;
-            if (rounds >= 2.f && (frac == 0.f || frac > 0.7f)) {
+            // many rounds (48,704 rows: 11.9 of 192-row tiles, 8.95 of 256-row ones): the persistent 256-row tiles, priced as
+            // in gemm_glds_dispatch (a 192-row tile costs 0.85 of a 256-row one; 476 -> 4xx us there)
+            const int t256 = N % 256 == 0 ? (N / 256) * ceil_div(M, 256) : 0;
+            static const int rope256 = [] { const char* e = getenv("VALLE_GEMM_ROPE256"); return e ? atoi(e) : 1; }();   // dev switch
+            const int pg256 = (t256 && rope256) ? pp_persist_grid(t256, K) : 0;
+            if (pg256 && (float)ceil_div(t256, pg256) < 0.85f * (float)ceil_div((N / 256) * ceil_div(M, 192), pg256)) {
+                gemm_pp256_bf16_kernel<GEMM_EPI_ROPE, true, 64, true><<<pg256, 512, 0, s>>>(X, W, rope, (const bf16*)pos, C, M, N, K, ldc, eps);
+            } else if (rounds >= 2.f && (frac == 0.f || frac > 0.7f)) {
                 dim3 g192(N / 256, ceil_div(M, 192));
                 const int pg = pp_persist_grid(g192.x * g192.y, K);
                 if (pg) gemm_pp256_bf16_kernel<GEMM_EPI_ROPE, true, 48, true><<<pg, 512, 0, s>>>(X, W, rope, (const bf16*)pos, C, M, N, K, ldc, eps);
