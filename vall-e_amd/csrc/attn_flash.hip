@@ -37,7 +37,22 @@ template <int QB>
 __global__ __launch_bounds__(256, 4) void attn_flash_bf16_kernel(FlashAddr A, int causal) {
     constexpr int QT = 64 * QB;                               // queries per workgroup
     // causal: the last query tiles have the most key tiles -- dispatch them first so the grid's tail is made of short ones
-    const int qt = causal ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // Workgroup lin (dispatch order: it lands on XCD lin mod 8) -> (query tile, head, utterance).  The query tiles of one
+    // (utterance, head) share its K/V rows: in the plain order they go to as many XCDs as there are tiles and every one of those
+    // L2s fetches the rows (6 tiles at 761 tokens: 300 MB over the fabric for 50 MB of K/V per pass); instead XCD x takes the
+    // (utterance, head) units x, x + 8, ... with all their query tiles.  FA_NO_XCD_ORDER: the plain order (dev A/B builds).
+    int qi = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+#ifndef FA_NO_XCD_ORDER
+    {
+        const int nq = gridDim.x, H = gridDim.y, nu8 = (int)(gridDim.y * gridDim.z) & ~7;
+        const int lin = blockIdx.x + nq * (blockIdx.y + H * blockIdx.z);
+        if (lin < nq * nu8) {
+            const int sl = lin >> 3, unit = (lin & 7) + 8 * (sl / nq);
+            qi = sl % nq; h = unit % H; b = unit / H;
+        }
+    }
+#endif
+    const int qt = causal ? (int)gridDim.x - 1 - qi : qi;
     int start = 0, T;
     if (A.cu) { start = A.cu[b]; T = A.cu[b + 1] - start; }
     else T = A.seqlens ? min(A.seqlens[b], A.T_fixed) : A.T_fixed;
