@@ -280,6 +280,38 @@ def test_sampler_known_answers(gpu_device):
         torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
 
 
+def test_cfg_combine_many_utterances_by_row_chunks(gpu_device):
+    """valle_cfg_combine from 8 utterances on runs two launches with 8 workgroups per utterance (partial sums per row chunk, added
+    up in order) instead of one workgroup per utterance: against the formula in fp64 (models/base.py cfg_logits: per-utterance
+    std of the whole block, samplers.py:186-199 semantics) and against the one-workgroup kernel called per utterance; ragged
+    lengths (shorter than the chunk count, empty, one row)."""
+    m = hip_model("tiny")
+    V, ld = 1025, 1032
+    lens = [450, 3, 0, 1, 449, 17, 450, 8, 9, 200, 7]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    g = torch.Generator().manual_seed(3)
+    pos = torch.zeros(int(off[-1]), ld); neg = torch.zeros_like(pos)
+    pos[:, :V] = torch.randn(int(off[-1]), V, generator=g) * 4
+    neg[:, :V] = pos[:, :V] + torch.randn(int(off[-1]), V, generator=g)
+    for strength, rescale in ((2.5, 0.75), (3.0, 0.0)):
+        p = pos.to(gpu_device).clone(); n = neg.to(gpu_device)
+        m.cfg_combine(p, n, V, off, strength, rescale)
+        got = p.cpu()
+        assert torch.equal(got[:, V:], pos[:, V:]), "padding columns were written"
+        for i, L_ in enumerate(lens):
+            if L_ == 0:
+                continue
+            a, b = int(off[i]), int(off[i + 1])
+            pp, nn = pos[a:b, :V].double(), neg[a:b, :V].double()
+            sm = nn + (pp - nn) * strength
+            if rescale > 0 and L_ * V > 1:
+                sm = sm * (rescale * (pp.std() / sm.std()) + (1 - rescale))
+            torch.testing.assert_close(got[a:b, :V].double(), sm, rtol=3e-6, atol=3e-6)
+            solo = pos[a:b].to(gpu_device).clone()
+            m.cfg_combine(solo, neg[a:b].to(gpu_device), V, np.array([0, L_], dtype=np.int32), strength, rescale)
+            torch.testing.assert_close(got[a:b], solo.cpu(), rtol=1e-6, atol=1e-6)
+
+
 def test_sampler_dynamic_temperature_and_dry(gpu_device):
     """valle_sample with dynamic temperature (samplers.py:128-141) and DRY (:248-275) against the reference's own
     outputs (samplers_kat2): greedy ids identical, score = softmax(processed)[id] within fp32 noise."""

@@ -777,11 +777,103 @@ __global__ __launch_bounds__(1024) void cfg_combine_kernel(float* __restrict__ p
     (void)stat;
 }
 
+// The same combination over whole utterances (NAR-len: 450 rows x 1,025 columns each) with CFG_CH workgroups per utterance
+// instead of one (64 utterances on one workgroup each left 3/4 of the chip idle: 446 us per call).  Phase 0: chunk c of
+// utterance i adds up its rows' four sums (double) into cfg_part[i][c]; phase 1: every chunk adds the CFG_CH partial sums up
+// in order -- the same value in every workgroup of the utterance -- and rewrites its rows.  cfg_part is a file-scope device
+// array (no allocation; calls that overlap on one GPU would race on it, like every stream-ordered workspace here).
+#define CFG_CH 8
+#define CFG_MAXB 2048
+static __device__ __align__(256) double cfg_part[CFG_MAXB * CFG_CH * 4];
+template <int PHASE>
+__global__ __launch_bounds__(1024) void cfg_combine_split_kernel(float* __restrict__ pos, const float* __restrict__ neg, int ld,
+                                                                 int vocab, const int32_t* __restrict__ row_a, double* part,
+                                                                 float strength, float rescale) {
+    const int i = blockIdx.x, c = blockIdx.y;
+    const int ra = row_a[i], rb = row_a[i + 1];
+    const long n = (long)(rb - ra) * vocab;
+    if (n <= 0) return;
+    const int per = (rb - ra + CFG_CH - 1) / CFG_CH;
+    const int r0 = ra + c * per, r1 = min(r0 + per, rb);
+    __shared__ double red[4][16];
+    if constexpr (PHASE == 0) {
+        double sp = 0, sm = 0, qp = 0, qm = 0;
+        for (int r = r0; r < r1; ++r) {
+            const float* pr = pos + (size_t)r * ld;
+            const float* nr = neg + (size_t)r * ld;
+            for (int v = threadIdx.x; v < vocab; v += 1024) {
+                const float p = pr[v], q = nr[v];
+                const double sd = (double)(q + (p - q) * strength);
+                sp += p; qp += (double)p * p; sm += sd; qm += sd * sd;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sp += __shfl_xor(sp, o, 64); sm += __shfl_xor(sm, o, 64); qp += __shfl_xor(qp, o, 64); qm += __shfl_xor(qm, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            const int w = threadIdx.x >> 6;
+            red[0][w] = sp; red[1][w] = sm; red[2][w] = qp; red[3][w] = qm;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            double t = 0;
+            for (int w = 0; w < 16; ++w) t += red[threadIdx.x][w];
+            part[((size_t)i * CFG_CH + c) * 4 + threadIdx.x] = t;
+        }
+    } else {
+        float factor = 1.0f;
+        if (rescale > 0.f) {
+            double t[4] = {0, 0, 0, 0};
+            for (int cc = 0; cc < CFG_CH; ++cc)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] += part[((size_t)i * CFG_CH + cc) * 4 + k];
+            const double vp = (t[2] - t[0] * t[0] / n) / (n - 1), vm = (t[3] - t[1] * t[1] / n) / (n - 1);
+            const float sdp = (float)sqrt(vp > 0 ? vp : 0), sdm = (float)sqrt(vm > 0 ? vm : 0);
+            factor = rescale * (sdp / sdm) + (1.0f - rescale);
+        }
+        for (int r = r0; r < r1; ++r) {
+            float* pr = pos + (size_t)r * ld;
+            const float* nr = neg + (size_t)r * ld;
+            for (int v = threadIdx.x; v < vocab; v += 1024) {
+                const float p = pr[v], q = nr[v];
+                float sv = q + (p - q) * strength;
+                if (rescale > 0.f) sv = sv * factor;
+                pr[v] = sv;
+            }
+        }
+    }
+}
+
+static int cfg_part_resolve(double** out) {
+    static double* ptr[64] = {};
+    int dev = 0;
+    VALLE_HIP_CHECK(hipGetDevice(&dev));
+    VALLE_REQUIRE(dev >= 0 && dev < 64, VALLE_E_ARG, "valle_cfg_combine: device %d", dev);
+    double* p = __atomic_load_n(&ptr[dev], __ATOMIC_ACQUIRE);
+    if (!p) {
+        VALLE_HIP_CHECK(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(cfg_part)));    // this device's copy of the array
+        __atomic_store_n(&ptr[dev], p, __ATOMIC_RELEASE);
+    }
+    *out = p;
+    return VALLE_OK;
+}
+
 extern "C" int valle_cfg_combine(float* pos, const float* neg, int ld, int vocab, const int32_t* row_off, int B,
                                  float strength, float rescale, void* stream) {
     VALLE_REQUIRE(pos && neg && row_off, VALLE_E_ARG, "valle_cfg_combine: null pointer");
     VALLE_REQUIRE(vocab > 0 && ld >= vocab, VALLE_E_ARG, "valle_cfg_combine: bad vocab/ld");
     if (B == 0) return VALLE_OK;
+    if (B >= 8 && B <= CFG_MAXB) {           // enough utterances for the row chunks to matter, few enough for the partial sums
+        double* part = nullptr;
+        int rc = cfg_part_resolve(&part);
+        if (rc != VALLE_OK) return rc;
+        const dim3 g(B, CFG_CH);
+        if (rescale > 0.f) cfg_combine_split_kernel<0><<<g, 1024, 0, (hipStream_t)stream>>>(pos, neg, ld, vocab, row_off, part, strength, rescale);
+        cfg_combine_split_kernel<1><<<g, 1024, 0, (hipStream_t)stream>>>(pos, neg, ld, vocab, row_off, part, strength, rescale);
+        VALLE_LAUNCH_CHECK();
+        return VALLE_OK;
+    }
     cfg_combine_kernel<false><<<B, 1024, 0, (hipStream_t)stream>>>(pos, neg, ld, vocab, row_off, nullptr, nullptr, 0, strength, rescale);
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
