@@ -195,7 +195,9 @@ int valle_sample_mirostat(const float* logits, int ld, int vocab, int rows, cons
 /* Classifier-free guidance (samplers.py:177-191) on fp32 logits, per utterance i over its
  * rows [row_off[i], row_off[i+1]): s = neg + (pos - neg) * strength; if rescale > 0,
  * s *= rescale * std(pos)/std(s) + (1 - rescale) with std the unbiased std over ALL
- * rows x vocab of that utterance.  Written in place into `pos`. */
+ * rows x vocab of that utterance.  Written in place into `pos`.  From 8 utterances on the work of an
+ * utterance is spread over 8 workgroups; their partial sums go through a 0.5-MB device array that the
+ * first such call on a (device, stream) allocates and the library keeps (not for use under graph capture). */
 int valle_cfg_combine(float* pos, const float* neg, int ld, int vocab, const int32_t* row_off, int B,
                       float strength, float rescale, void* stream);
 

@@ -3,6 +3,9 @@
 //   cfg_combine   samplers.py:177-191
 //   mask_lowest   models/ar_nar.py:358-365
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 
 #define SAMP_MAXV 2048
 #define SAMP_THREADS 256
@@ -780,11 +783,10 @@ __global__ __launch_bounds__(1024) void cfg_combine_kernel(float* __restrict__ p
 // The same combination over whole utterances (NAR-len: 450 rows x 1,025 columns each) with CFG_CH workgroups per utterance
 // instead of one (64 utterances on one workgroup each left 3/4 of the chip idle: 446 us per call).  Phase 0: chunk c of
 // utterance i adds up its rows' four sums (double) into cfg_part[i][c]; phase 1: every chunk adds the CFG_CH partial sums up
-// in order -- the same value in every workgroup of the utterance -- and rewrites its rows.  cfg_part is a file-scope device
-// array (no allocation; calls that overlap on one GPU would race on it, like every stream-ordered workspace here).
+// in order -- the same value in every workgroup of the utterance -- and rewrites its rows.  The partial sums live in a small
+// device array per (device, stream) (cfg_part_resolve).
 #define CFG_CH 8
 #define CFG_MAXB 2048
-static __device__ __align__(256) double cfg_part[CFG_MAXB * CFG_CH * 4];
 template <int PHASE>
 __global__ __launch_bounds__(1024) void cfg_combine_split_kernel(float* __restrict__ pos, const float* __restrict__ neg, int ld,
                                                                  int vocab, const int32_t* __restrict__ row_a, double* part,
@@ -845,16 +847,16 @@ __global__ __launch_bounds__(1024) void cfg_combine_split_kernel(float* __restri
     }
 }
 
-static int cfg_part_resolve(double** out) {
-    static double* ptr[64] = {};
+// one array of partial sums per (device, stream), allocated at the stream's first call and kept: calls on different streams
+// (one per host thread in TTS.batched_inference) must not share it, calls on one stream are ordered
+static int cfg_part_resolve(hipStream_t s, double** out) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, double*> parts;
     int dev = 0;
     VALLE_HIP_CHECK(hipGetDevice(&dev));
-    VALLE_REQUIRE(dev >= 0 && dev < 64, VALLE_E_ARG, "valle_cfg_combine: device %d", dev);
-    double* p = __atomic_load_n(&ptr[dev], __ATOMIC_ACQUIRE);
-    if (!p) {
-        VALLE_HIP_CHECK(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(cfg_part)));    // this device's copy of the array
-        __atomic_store_n(&ptr[dev], p, __ATOMIC_RELEASE);
-    }
+    std::lock_guard<std::mutex> lock(mu);
+    double*& p = parts[std::make_pair(dev, s)];
+    if (!p) VALLE_HIP_CHECK(hipMalloc((void**)&p, sizeof(double) * CFG_MAXB * CFG_CH * 4));
     *out = p;
     return VALLE_OK;
 }
@@ -866,7 +868,7 @@ extern "C" int valle_cfg_combine(float* pos, const float* neg, int ld, int vocab
     if (B == 0) return VALLE_OK;
     if (B >= 8 && B <= CFG_MAXB) {           // enough utterances for the row chunks to matter, few enough for the partial sums
         double* part = nullptr;
-        int rc = cfg_part_resolve(&part);
+        int rc = cfg_part_resolve((hipStream_t)stream, &part);
         if (rc != VALLE_OK) return rc;
         const dim3 g(B, CFG_CH);
         if (rescale > 0.f) cfg_combine_split_kernel<0><<<g, 1024, 0, (hipStream_t)stream>>>(pos, neg, ld, vocab, row_off, part, strength, rescale);
