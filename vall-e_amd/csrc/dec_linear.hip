@@ -193,8 +193,8 @@ __global__ __launch_bounds__(64 * NWK) void dec_wave_kernel(const bf16* __restri
             STORE_OUT(reinterpret_cast<bf16x4*>((bf16*)pOut + (size_t)mt * 16 * N + dec_frag_off<1>(fr, n, N)), o);
         } else if constexpr (EPI == VALLE_EPI_GEGLU) {
             bf16x2 o;
-            o[0] = (bf16)((float)(bf16)gelu_erf((float)(bf16)sum[0]) * (float)(bf16)sum[1]);
-            o[1] = (bf16)((float)(bf16)gelu_erf((float)(bf16)sum[2]) * (float)(bf16)sum[3]);
+            o[0] = (bf16)((float)(bf16)gelu_erf_bf16out((float)(bf16)sum[0]) * (float)(bf16)sum[1]);
+            o[1] = (bf16)((float)(bf16)gelu_erf_bf16out((float)(bf16)sum[2]) * (float)(bf16)sum[3]);
             STORE_OUT(reinterpret_cast<bf16x2*>((bf16*)pOut + (size_t)mt * 16 * (N >> 1) + dec_frag_off<DEC_S_DOWN>(fr, n >> 1, N >> 1)), o);
         } else if constexpr (EPI == VALLE_EPI_F32OUT) {
             float* o = (float*)pOut + (size_t)m * a.ldo + n;

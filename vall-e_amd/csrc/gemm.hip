@@ -94,8 +94,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[NI][MJ], int nw0, int
                 typedef T vec2 __attribute__((ext_vector_type(2)));
                 vec2 o;
                 // reference: act(gate) and up are each rounded to the storage type before the product
-                o[0] = from_f32<T>(to_f32<T>(from_f32<T>(gelu_erf(to_f32<T>(from_f32<T>(v[0]))))) * to_f32<T>(from_f32<T>(v[1])));
-                o[1] = from_f32<T>(to_f32<T>(from_f32<T>(gelu_erf(to_f32<T>(from_f32<T>(v[2]))))) * to_f32<T>(from_f32<T>(v[3])));
+                o[0] = from_f32<T>(to_f32<T>(from_f32<T>(gelu_act<T>(to_f32<T>(from_f32<T>(v[0]))))) * to_f32<T>(from_f32<T>(v[1])));
+                o[1] = from_f32<T>(to_f32<T>(from_f32<T>(gelu_act<T>(to_f32<T>(from_f32<T>(v[2]))))) * to_f32<T>(from_f32<T>(v[3])));
                 *reinterpret_cast<vec2*>(C + (size_t)m * ldc + (nb >> 1)) = o;
             } else {
                 T* C = (T*)Cout;
@@ -112,7 +112,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[NI][MJ], int nw0, int
                         for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(to_f32<T>(rr[r]) + to_f32<T>(from_f32<T>(v[r] + bv[r])));
                     } else if constexpr (EPI == VALLE_EPI_GELU) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(gelu_erf(to_f32<T>(from_f32<T>(v[r] + bv[r]))));
+                        for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(gelu_act<T>(to_f32<T>(from_f32<T>(v[r] + bv[r]))));
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r] + bv[r]);
@@ -125,7 +125,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[NI][MJ], int nw0, int
                         float o = v[r];
                         if constexpr (EPI == VALLE_EPI_RESID) o = to_f32<T>(resid[(size_t)m * ldc + nb + r]) + to_f32<T>(from_f32<T>(o));
                         else if constexpr (EPI == VALLE_EPI_RESID_BIAS) o = to_f32<T>(resid[(size_t)m * ldc + nb + r]) + to_f32<T>(from_f32<T>(o + bv[r]));
-                        else if constexpr (EPI == VALLE_EPI_GELU) o = gelu_erf(to_f32<T>(from_f32<T>(o + bv[r])));
+                        else if constexpr (EPI == VALLE_EPI_GELU) o = gelu_act<T>(to_f32<T>(from_f32<T>(o + bv[r])));
                         else if constexpr (EPI == VALLE_EPI_STORE) o += bv[r];
                         C[(size_t)m * ldc + nb + r] = from_f32<T>(o);
                     }
