@@ -195,11 +195,17 @@ int valle_sample_mirostat(const float* logits, int ld, int vocab, int rows, cons
 /* Classifier-free guidance (samplers.py:177-191) on fp32 logits, per utterance i over its
  * rows [row_off[i], row_off[i+1]): s = neg + (pos - neg) * strength; if rescale > 0,
  * s *= rescale * std(pos)/std(s) + (1 - rescale) with std the unbiased std over ALL
- * rows x vocab of that utterance.  Written in place into `pos`.  From 8 utterances on the work of an
- * utterance is spread over 8 workgroups; their partial sums go through a 0.5-MB device array that the
- * first such call on a (device, stream) allocates and the library keeps (not for use under graph capture). */
+ * rows x vocab of that utterance.  Written in place into `pos`.  One workgroup per utterance. */
 int valle_cfg_combine(float* pos, const float* neg, int ld, int vocab, const int32_t* row_off, int B,
                       float strength, float rescale, void* stream);
+
+/* valle_cfg_combine with the work of an utterance spread over 8 workgroups (NAR-len: 64 utterances x 450 rows left 3/4 of
+ * the chip idle on one workgroup each): two launches, the row chunks' partial sums (double) go through `workspace`
+ * (valle_cfg_combine_workspace_bytes(B), 8-byte aligned) and are added up in chunk order by every workgroup of the utterance.
+ * Same formula; the sums are added in another order than valle_cfg_combine's (fp64: the factor agrees to ~1e-7). */
+size_t valle_cfg_combine_workspace_bytes(int B);
+int valle_cfg_combine_ws(float* pos, const float* neg, int ld, int vocab, const int32_t* row_off, int B,
+                         float strength, float rescale, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The guidance of the AR loop (models/ar_nar.py:785-800 -> samplers.py:177-191): utterance i's rows are
  * [row_start[i], row_start[i] + row_count[i]) of two READ-ONLY row matrices (the per-step logit histories of the

@@ -83,6 +83,8 @@ SIGNATURES = {
     "valle_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                              C.POINTER(SampleParams), c_void_p, c_void_p, c_void_p]),
     "valle_cfg_combine": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_float, c_float, c_void_p]),
+    "valle_cfg_combine_workspace_bytes": (c_size_t, [c_int]),
+    "valle_cfg_combine_ws": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_float, c_float, c_void_p, c_size_t, c_void_p]),
     "valle_cfg_combine_last": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_int, c_void_p]),
     "valle_sample_append": (c_int, [c_void_p, c_int, c_int, c_int, C.POINTER(SampleParams), c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -3,9 +3,6 @@
 //   cfg_combine   samplers.py:177-191
 //   mask_lowest   models/ar_nar.py:358-365
 #include "common.h"
-#include <map>
-#include <mutex>
-#include <utility>
 
 #define SAMP_MAXV 2048
 #define SAMP_THREADS 256
@@ -783,10 +780,9 @@ __global__ __launch_bounds__(1024) void cfg_combine_kernel(float* __restrict__ p
 // The same combination over whole utterances (NAR-len: 450 rows x 1,025 columns each) with CFG_CH workgroups per utterance
 // instead of one (64 utterances on one workgroup each left 3/4 of the chip idle: 446 us per call).  Phase 0: chunk c of
 // utterance i adds up its rows' four sums (double) into cfg_part[i][c]; phase 1: every chunk adds the CFG_CH partial sums up
-// in order -- the same value in every workgroup of the utterance -- and rewrites its rows.  The partial sums live in a small
-// device array per (device, stream) (cfg_part_resolve).
+// in order -- the same value in every workgroup of the utterance -- and rewrites its rows.  The partial sums live in the
+// caller's workspace (valle_cfg_combine_ws).
 #define CFG_CH 8
-#define CFG_MAXB 2048
 template <int PHASE>
 __global__ __launch_bounds__(1024) void cfg_combine_split_kernel(float* __restrict__ pos, const float* __restrict__ neg, int ld,
                                                                  int vocab, const int32_t* __restrict__ row_a, double* part,
@@ -847,36 +843,30 @@ __global__ __launch_bounds__(1024) void cfg_combine_split_kernel(float* __restri
     }
 }
 
-// one array of partial sums per (device, stream), allocated at the stream's first call and kept: calls on different streams
-// (one per host thread in TTS.batched_inference) must not share it, calls on one stream are ordered
-static int cfg_part_resolve(hipStream_t s, double** out) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, double*> parts;
-    int dev = 0;
-    VALLE_HIP_CHECK(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(mu);
-    double*& p = parts[std::make_pair(dev, s)];
-    if (!p) VALLE_HIP_CHECK(hipMalloc((void**)&p, sizeof(double) * CFG_MAXB * CFG_CH * 4));
-    *out = p;
-    return VALLE_OK;
-}
-
 extern "C" int valle_cfg_combine(float* pos, const float* neg, int ld, int vocab, const int32_t* row_off, int B,
                                  float strength, float rescale, void* stream) {
     VALLE_REQUIRE(pos && neg && row_off, VALLE_E_ARG, "valle_cfg_combine: null pointer");
     VALLE_REQUIRE(vocab > 0 && ld >= vocab, VALLE_E_ARG, "valle_cfg_combine: bad vocab/ld");
     if (B == 0) return VALLE_OK;
-    if (B >= 8 && B <= CFG_MAXB) {           // enough utterances for the row chunks to matter, few enough for the partial sums
-        double* part = nullptr;
-        int rc = cfg_part_resolve((hipStream_t)stream, &part);
-        if (rc != VALLE_OK) return rc;
-        const dim3 g(B, CFG_CH);
-        if (rescale > 0.f) cfg_combine_split_kernel<0><<<g, 1024, 0, (hipStream_t)stream>>>(pos, neg, ld, vocab, row_off, part, strength, rescale);
-        cfg_combine_split_kernel<1><<<g, 1024, 0, (hipStream_t)stream>>>(pos, neg, ld, vocab, row_off, part, strength, rescale);
-        VALLE_LAUNCH_CHECK();
-        return VALLE_OK;
-    }
     cfg_combine_kernel<false><<<B, 1024, 0, (hipStream_t)stream>>>(pos, neg, ld, vocab, row_off, nullptr, nullptr, 0, strength, rescale);
+    VALLE_LAUNCH_CHECK();
+    return VALLE_OK;
+}
+
+extern "C" size_t valle_cfg_combine_workspace_bytes(int B) { return (size_t)(B > 0 ? B : 0) * CFG_CH * 4 * sizeof(double); }
+
+extern "C" int valle_cfg_combine_ws(float* pos, const float* neg, int ld, int vocab, const int32_t* row_off, int B,
+                                    float strength, float rescale, void* workspace, size_t workspace_bytes, void* stream) {
+    VALLE_REQUIRE(pos && neg && row_off && workspace, VALLE_E_ARG, "valle_cfg_combine_ws: null pointer");
+    VALLE_REQUIRE(vocab > 0 && ld >= vocab, VALLE_E_ARG, "valle_cfg_combine_ws: bad vocab/ld");
+    VALLE_REQUIRE(B >= 0 && B <= 65535, VALLE_E_ARG, "valle_cfg_combine_ws: %d utterances", B);
+    VALLE_REQUIRE(workspace_bytes >= valle_cfg_combine_workspace_bytes(B) && ((uintptr_t)workspace & 7) == 0, VALLE_E_WORKSPACE,
+                  "valle_cfg_combine_ws: workspace %zu B too small or misaligned (need %zu)", workspace_bytes, valle_cfg_combine_workspace_bytes(B));
+    if (B == 0) return VALLE_OK;
+    const dim3 g(B, CFG_CH);
+    double* part = (double*)workspace;
+    if (rescale > 0.f) cfg_combine_split_kernel<0><<<g, 1024, 0, (hipStream_t)stream>>>(pos, neg, ld, vocab, row_off, part, strength, rescale);
+    cfg_combine_split_kernel<1><<<g, 1024, 0, (hipStream_t)stream>>>(pos, neg, ld, vocab, row_off, part, strength, rescale);
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
 }

@@ -829,8 +829,15 @@ class Base:
     def cfg_combine(self, pos_logits, neg_logits, vocab, row_off, strength, rescale):
         lib = L.load()
         off = self._i32(row_off)
+        B = len(row_off) - 1
+        if B >= 8:      # many utterances (NAR-len batches): an utterance's rows over 8 workgroups, partial sums through a workspace
+            nbytes = int(lib.valle_cfg_combine_workspace_bytes(B))
+            ws = torch.empty(nbytes // 8, dtype=torch.float64, device=self.device)   # (stream-ordered: the allocator keeps it until the launches ran)
+            L.check(lib.valle_cfg_combine_ws(L.ptr(pos_logits), L.ptr(neg_logits), pos_logits.shape[1], vocab, L.ptr(off), B,
+                                             float(strength), float(rescale), L.ptr(ws), nbytes, L.stream_ptr(self.device)))
+            return pos_logits
         L.check(lib.valle_cfg_combine(L.ptr(pos_logits), L.ptr(neg_logits), pos_logits.shape[1], vocab, L.ptr(off),
-                                      len(row_off) - 1, float(strength), float(rescale), L.stream_ptr(self.device)))
+                                      B, float(strength), float(rescale), L.stream_ptr(self.device)))
         return pos_logits
 
 
