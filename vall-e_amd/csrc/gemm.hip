@@ -243,6 +243,9 @@ __device__ __forceinline__ float row_rinv(float ss, int K, float eps) {
     return 1.0f / sqrtf(ss * (1.0f / (float)K) + eps);
 }
 
+#ifndef GLDS_SWZ_MAX_NX
+#define GLDS_SWZ_MAX_NX 24
+#endif
 template <int EPI, bool NORM = false>
 __global__ __launch_bounds__(256) void gemm_glds_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ W,
                                                              const void* __restrict__ bias, const bf16* resid,
@@ -252,7 +255,15 @@ __global__ __launch_bounds__(256) void gemm_glds_bf16_kernel(const bf16* __restr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wm = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
+    // (workgroups dealt to XCDs by row tile when there are few column tiles: see tile_nm in gemm_pp256_bf16_kernel)
+    int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
+    {
+        const int nxt = gridDim.x, lin = blockIdx.x + nxt * blockIdx.y;
+        if (nxt <= GLDS_SWZ_MAX_NX && lin < nxt * ((int)gridDim.y & ~7)) {
+            const int sl = lin >> 3;
+            n0 = (sl % nxt) * 128; m0 = ((lin & 7) + 8 * (sl / nxt)) * 128;
+        }
+    }
 
     f32x4 acc[4][4];
 #pragma unroll
