@@ -199,7 +199,7 @@ int valle_sample_mirostat(const float* logits, int ld, int vocab, int rows, cons
 int valle_cfg_combine(float* pos, const float* neg, int ld, int vocab, const int32_t* row_off, int B,
                       float strength, float rescale, void* stream);
 
-/* valle_cfg_combine with the work of an utterance spread over 8 workgroups (NAR-len: 64 utterances x 450 rows left 3/4 of
+/* valle_cfg_combine (call sites models/ar_nar.py:433, :574) with the work of an utterance spread over 8 workgroups (NAR-len: 64 utterances x 450 rows left 3/4 of
  * the chip idle on one workgroup each): two launches, the row chunks' partial sums (double) go through `workspace`
  * (valle_cfg_combine_workspace_bytes(B), 8-byte aligned) and are added up in chunk order by every workgroup of the utterance.
  * Same formula; the sums are added in another order than valle_cfg_combine's (fp64: the factor agrees to ~1e-7). */
