@@ -177,50 +177,90 @@ extern "C" int valle_v2_level_sum(const void* y, const float* lw, int L, int n, 
 }
 
 // Guidance on (levels, rows, vocab) logits (samplers.py:177-191 with a 3-D input: dims = (1,), the ROWS): one workgroup per
-// (utterance, level, 64 vocabulary columns); a lane owns a column, the four waves split the rows.  Unbiased standard
-// deviations by mean-then-centred-squares; one row gives nan, as torch.std does.
-__global__ __launch_bounds__(256) void cfg_combine_cols_kernel(float* __restrict__ pos, const float* __restrict__ neg, int ld,
+// (utterance, level, 64 vocabulary columns); a lane owns a column, the eight waves split the rows (wave w: rows w, w + 8, ...).
+// Unbiased standard deviations by mean-then-centred-squares; one row gives nan, as torch.std does.  An utterance of up to
+// 8 x CC_MAXR rows keeps its column's values in registers between the three passes (one read of pos / neg instead of three);
+// longer ones re-read them.  Both forms do the same additions in the same order.
+#define CC_MAXR 64
+__global__ __launch_bounds__(512) void cfg_combine_cols_kernel(float* __restrict__ pos, const float* __restrict__ neg, int ld,
                                                                int vocab, int rows_total, const int32_t* __restrict__ row_off,
                                                                int L, float strength, float rescale) {
     const int i = blockIdx.y / L, l = blockIdx.y - i * L;
     const int r0 = row_off[i], n = row_off[i + 1] - r0;
-    const int v = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const int c = threadIdx.x & 63, v = blockIdx.x * 64 + c, w = threadIdx.x >> 6;
     const bool live = v < vocab;
     float* p = pos + ((size_t)l * rows_total + r0) * ld + v;
     const float* q = neg + ((size_t)l * rows_total + r0) * ld + v;
-    __shared__ float red[2][4][64];
+    __shared__ float red[2][8][64];
+    auto fold = [&](float a, float b, float& oa, float& ob) {          // sums over the 8 waves, in wave order
+        __syncthreads();
+        red[0][w][c] = a; red[1][w][c] = b;
+        __syncthreads();
+        oa = 0.f; ob = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { oa += red[0][u][c]; ob += red[1][u][c]; }
+    };
+    auto mix = [&](float a, float b) { return __fadd_rn(b, __fmul_rn(__fadd_rn(a, -b), strength)); };
+    if (n <= 8 * CC_MAXR) {                                            // (uniform per workgroup)
+        float pa[CC_MAXR], sa[CC_MAXR];
+#pragma unroll
+        for (int k = 0; k < CC_MAXR; ++k) {
+            const int r = w + 8 * k;
+            float a = 0.f, b = 0.f;
+            if (live && r < n) { a = p[(size_t)r * ld]; b = q[(size_t)r * ld]; }
+            pa[k] = a; sa[k] = mix(a, b);
+        }
+        float sp = 0.f, ssum = 0.f;
+#pragma unroll
+        for (int k = 0; k < CC_MAXR; ++k)
+            if (live && w + 8 * k < n) { sp += pa[k]; ssum += sa[k]; }
+        float tp, ts;
+        fold(sp, ssum, tp, ts);
+        const float mp = tp / (float)n, ms = ts / (float)n;
+        float factor = 1.f;
+        if (rescale > 0.f) {
+            float vp = 0.f, vs = 0.f;
+#pragma unroll
+            for (int k = 0; k < CC_MAXR; ++k)
+                if (live && w + 8 * k < n) { vp += (pa[k] - mp) * (pa[k] - mp); vs += (sa[k] - ms) * (sa[k] - ms); }
+            float qp, qs;
+            fold(vp, vs, qp, qs);
+            factor = __fadd_rn(__fmul_rn(rescale, sqrtf(qp / (float)(n - 1)) / sqrtf(qs / (float)(n - 1))), 1.f - rescale);
+        }
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < CC_MAXR; ++k) {
+                const int r = w + 8 * k;
+                if (r < n) p[(size_t)r * ld] = rescale > 0.f ? __fmul_rn(sa[k], factor) : sa[k];
+            }
+        }
+        return;
+    }
     float sp = 0.f, ssum = 0.f;
     if (live)
-        for (int r = w; r < n; r += 4) {
+        for (int r = w; r < n; r += 8) {
             const float a = p[(size_t)r * ld], b = q[(size_t)r * ld];
-            sp += a; ssum += __fadd_rn(b, __fmul_rn(__fadd_rn(a, -b), strength));
+            sp += a; ssum += mix(a, b);
         }
-    red[0][w][threadIdx.x & 63] = sp; red[1][w][threadIdx.x & 63] = ssum;
-    __syncthreads();
-    const int c = threadIdx.x & 63;
-    const float mp = (red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]) / (float)n;
-    const float ms = (red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]) / (float)n;
-    __syncthreads();
-    float vp = 0.f, vs = 0.f;
-    if (live && rescale > 0.f)
-        for (int r = w; r < n; r += 4) {
-            const float a = p[(size_t)r * ld], b = q[(size_t)r * ld];
-            const float s = __fadd_rn(b, __fmul_rn(__fadd_rn(a, -b), strength));
-            vp += (a - mp) * (a - mp); vs += (s - ms) * (s - ms);
-        }
-    red[0][w][c] = vp; red[1][w][c] = vs;
-    __syncthreads();
+    float tp, ts;
+    fold(sp, ssum, tp, ts);
+    const float mp = tp / (float)n, ms = ts / (float)n;
     float factor = 1.f;
     if (rescale > 0.f) {
-        const float sdp = sqrtf((red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]) / (float)(n - 1));
-        const float sds = sqrtf((red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]) / (float)(n - 1));
-        factor = __fadd_rn(__fmul_rn(rescale, sdp / sds), 1.f - rescale);
+        float vp = 0.f, vs = 0.f;
+        if (live)
+            for (int r = w; r < n; r += 8) {
+                const float a = p[(size_t)r * ld], sv = mix(a, q[(size_t)r * ld]);
+                vp += (a - mp) * (a - mp); vs += (sv - ms) * (sv - ms);
+            }
+        float qp, qs;
+        fold(vp, vs, qp, qs);
+        factor = __fadd_rn(__fmul_rn(rescale, sqrtf(qp / (float)(n - 1)) / sqrtf(qs / (float)(n - 1))), 1.f - rescale);
     }
     if (live)
-        for (int r = w; r < n; r += 4) {
-            const float a = p[(size_t)r * ld], b = q[(size_t)r * ld];
-            const float s = __fadd_rn(b, __fmul_rn(__fadd_rn(a, -b), strength));
-            p[(size_t)r * ld] = rescale > 0.f ? __fmul_rn(s, factor) : s;
+        for (int r = w; r < n; r += 8) {
+            const float sv = mix(p[(size_t)r * ld], q[(size_t)r * ld]);
+            p[(size_t)r * ld] = rescale > 0.f ? __fmul_rn(sv, factor) : sv;
         }
 }
 
@@ -232,7 +272,7 @@ extern "C" int valle_cfg_combine_cols(float* pos, const float* neg, int ld, int 
     if (B == 0 || rows_total == 0) return VALLE_OK;
     VALLE_REQUIRE((long)B * L <= 65535, VALLE_E_ARG, "valle_cfg_combine_cols: B * L = %ld exceeds the grid", (long)B * L);
     dim3 grid(ceil_div(vocab, 64), B * L);
-    cfg_combine_cols_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(pos, neg, ld, vocab, rows_total, row_off, L, strength, rescale);
+    cfg_combine_cols_kernel<<<grid, 512, 0, (hipStream_t)stream>>>(pos, neg, ld, vocab, rows_total, row_off, L, strength, rescale);
     VALLE_LAUNCH_CHECK();
     return VALLE_OK;
 }
