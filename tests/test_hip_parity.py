@@ -280,6 +280,63 @@ def test_sampler_known_answers(gpu_device):
         torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(40000, 768, 1024, "resid"), (33000, 1024, 1024, "resid"), (5000, 4352, 128, "geglu"),
+                                        (20000, 4096, 192, "store"), (16500, 3072, 1024, "rope")])
+def test_pingpong_gemm_odd_grids(gpu_device, M, N, K, epi):
+    """The ping-pong GEMM's tile walk on grids that are not whole rounds: persistent launches whose tile count is no multiple
+    of the CU count, the XCD-dealt order with a remainder of row tiles (m tiles not a multiple of 8) and with a ragged last n
+    tile, two K-tiles only, an odd number of K-tiles (one tile per workgroup).  Every output row against fp64, and the first
+    rows bit for bit against a call on those rows alone (another kernel / another grid, same arithmetic per row)."""
+    from vall_e_amd import _lib as L
+    lib = L.load()
+    bf = L.dtype_code(torch.bfloat16)
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16().to(gpu_device)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(gpu_device)
+    m_small = 700
+    outs = []
+    for rows in (M, m_small):
+        if epi == "resid":
+            res = torch.randn(M, N, generator=torch.Generator().manual_seed(1)).bfloat16().to(gpu_device)
+            c = torch.zeros((rows + 1, N), dtype=torch.bfloat16, device=gpu_device)
+            L.check(lib.valle_gemm(L.ptr(x), L.ptr(w), None, L.ptr(res), L.ptr(c), rows, N, K, N, L.EPI_RESID, bf, L.stream_ptr()))
+        elif epi == "geglu":
+            c = torch.zeros((rows + 1, N // 2), dtype=torch.bfloat16, device=gpu_device)
+            L.check(lib.valle_gemm_normed(L.ptr(x), L.ptr(w), L.ptr(c), rows, N, K, N // 2, L.EPI_GEGLU, 1e-6, None, None, L.stream_ptr()))
+        elif epi == "store":
+            c = torch.zeros((rows + 1, N), dtype=torch.bfloat16, device=gpu_device)
+            L.check(lib.valle_gemm(L.ptr(x), L.ptr(w), None, None, L.ptr(c), rows, N, K, N, L.EPI_STORE, bf, L.stream_ptr()))
+        else:
+            inv = 1.0 / (10000.0 ** (torch.arange(0, 64, 2).float() / 64))
+            fr = torch.arange(1024).float()[:, None] * inv[None, :]
+            rope = torch.stack((fr.cos(), fr.sin()), dim=-1).contiguous().to(gpu_device)
+            pos = (torch.arange(M, dtype=torch.int32) % 1000).to(gpu_device)
+            c = torch.zeros((rows + 1, N), dtype=torch.bfloat16, device=gpu_device)
+            L.check(lib.valle_gemm_normed(L.ptr(x), L.ptr(w), L.ptr(c), rows, N, K, N, L.EPI_STORE, 1e-6, L.ptr(rope), L.ptr(pos), L.stream_ptr()))
+        assert (c[rows:] == 0).all(), "rows behind M were written"
+        outs.append(c)
+    assert torch.equal(outs[0][:m_small].view(torch.int16).cpu(), outs[1][:m_small].view(torch.int16).cpu())
+    big = outs[0][:M]
+    # fp64 on a sample of rows from every part of the walk (first / last tiles, the remainder behind the XCD-dealt part)
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M // 2, M // 2 + 300), torch.arange(M - 300, M)]).to(gpu_device)
+    xd, wd = x[rows].double(), w.double()
+    acc = xd @ wd.T
+    if epi == "resid":
+        want = res[rows].double() + acc
+    elif epi == "geglu":
+        acc = (xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-6)) @ wd.T
+        want = torch.nn.functional.gelu(acc[:, 0::2]) * acc[:, 1::2]
+    elif epi == "store":
+        want = acc
+    else:
+        acc = (xd * torch.rsqrt(xd.pow(2).mean(-1, keepdim=True) + 1e-6)) @ wd.T
+        want = acc[:, 2048:]                                                    # the v part is not rotated
+        big = big[:, 2048:]
+    got = big[rows].double()
+    assert ((got - want).norm() / want.norm()).item() < 1e-2
+    assert (got - want).abs().max().item() < 0.25 * max(1.0, want.abs().max().item())
+
+
 def test_bf16_gelu_over_every_bf16_input(gpu_device):
     """The bf16 epilogues' erf GELU (gelu_erf_bf16out: erfc by Abramowitz & Stegun 7.1.26, transformers ACT2FN["gelu"] semantics,
     reference models/base.py:479) on EVERY finite bf16 input, through valle_gemm(EPI_GELU) with a one-hot product: against the
